@@ -1,0 +1,90 @@
+"""ctypes binding of libaligner_amd.so (the C ABI declared in include/aligner_amd.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C aligner_amd/csrc`
+and is the ONLY implementation of the hot path: there is no CPU or PyTorch
+fallback anywhere in this package.  If the library is missing, or there is no
+GPU, the product entry points raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaligner_amd.so")
+
+# dtype codes (include/aligner_amd.h)
+DT_F32, DT_F16, DT_BF16, DT_F64, DT_I32, DT_U8, DT_I64 = range(7)
+
+F_STRICT_MASK = 1
+F_COMPAT_TXGTTY = 2
+F_FORCE_GENERIC = 4
+
+ST_BAD_LENGTHS = 1
+ST_CLAMPED = 2
+ST_INTERNAL = 4
+
+SIM_L2 = 0
+SIM_DOT = 1
+
+_c = ctypes
+_vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); every symbol include/aligner_amd.h declares
+SIGNATURES = {
+    "aligner_abi_version": (_i, []),
+    "aligner_last_error": (_c.c_char_p, []),
+    "aligner_device_count": (_i, []),
+    "aligner_maxpath_workspace_bytes": (_sz, [_i, _i, _i]),
+    "aligner_lengths_from_mask": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "aligner_maxpath_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,
+                                 _i, _i, _i, _f, _i, _vp]),
+    "aligner_maxpath_forward_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                         _i, _i, _i, _f, _i, _vp]),
+    "aligner_maxpath_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "aligner_maxpath_read_status": (_i, [_vp, _vp, _vp]),
+    "aligner_maxpath_host_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
+    "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "aligner_conv1d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+class AlignerError(RuntimeError):
+    """A C-ABI call returned a negative ALIGNER_E* code."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libaligner_amd error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library, failing loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C aligner_amd/csrc`. aligner_amd has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)            # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().aligner_last_error()
+        raise AlignerError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def require_gpu() -> None:
+    lib = load()
+    if lib.aligner_device_count() < 1:
+        raise RuntimeError("aligner_amd needs an AMD GPU (gfx950): no HIP device is visible and "
+                           "there is deliberately no CPU fallback")

@@ -1,0 +1,40 @@
+// Entry points that are not tied to one kernel family: versioning, error text,
+// device probing.  Part of libaligner_amd.so (see include/aligner_amd.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "common.h"
+
+namespace aligner {
+
+char *error_buffer() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+}  // namespace aligner
+
+extern "C" {
+
+int aligner_abi_version(void) { return ALIGNER_ABI_VERSION; }
+
+const char *aligner_last_error(void) { return aligner::error_buffer(); }
+
+int aligner_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// Shared host-side helpers for libaligner_amd.so (error reporting, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "aligner_amd.h"
+
+namespace aligner {
+
+// thread-local message behind aligner_last_error()
+char *error_buffer();
+int   fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define ALIGNER_HIP_CHECK(expr)                                                        \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess)                                                          \
+            return ::aligner::fail(ALIGNER_EHIP, "%s failed: %s (%s:%d)", #expr,       \
+                                   hipGetErrorString(_e), __FILE__, __LINE__);         \
+    } while (0)
+
+inline int dtype_size(int dt) {
+    switch (dt) {
+        case ALIGNER_DT_F32: return 4;
+        case ALIGNER_DT_F16: return 2;
+        case ALIGNER_DT_BF16: return 2;
+        case ALIGNER_DT_F64: return 8;
+        case ALIGNER_DT_I32: return 4;
+        case ALIGNER_DT_U8: return 1;
+        case ALIGNER_DT_I64: return 8;
+        default: return 0;
+    }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace aligner

@@ -1,0 +1,122 @@
+"""Soft-attention front end (OTA-style alignment encoder) on the HIP path.
+
+Build-defined spec (the reference snapshot only links the paper,
+README.md:50):
+
+    K = Conv1d(C_text -> 2 C_text, k=3) -> ReLU -> Conv1d(2 C_text -> C_att, k=1)      text [B,C_text,T_text]
+    Q = Conv1d(C_mel -> 2 C_mel, k=3) -> ReLU -> Conv1d(2 C_mel -> C_mel, k=1) -> ReLU
+          -> Conv1d(C_mel -> C_att, k=1)                                                mel  [B,C_mel,T_mel]
+    logit[b,i,j] = -temperature * sum_c (Q[b,c,j] - K[b,c,i])^2
+    logp = log_softmax over the text axis i (+ log(prior + 1e-8));  layout [B,T_text,T_mel]
+    hard = maximum_path(logp, mask)
+
+All arithmetic runs in libaligner_amd.so; torch only owns the buffers.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be a GPU tensor")
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """y = act(conv1d(x, weight, bias, padding=K//2)); x [B,Cin,T], weight [Cout,Cin,K], K in {1,3,5}."""
+    _lib.require_gpu()
+    x = _chk(x, "x"); weight = _chk(weight, "weight")
+    bias = _chk(bias, "bias") if bias is not None else None
+    B, Cin, T = x.shape
+    Cout, Cin2, K = weight.shape
+    if Cin2 != Cin:
+        raise ValueError("channel mismatch")
+    y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().aligner_conv1d_f32(x.data_ptr(), weight.data_ptr(),
+                                                  None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                  B, Cin, Cout, T, K, int(relu), _stream(x.device)))
+    return y
+
+
+def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optional[torch.Tensor] = None,
+                   prior: Optional[torch.Tensor] = None, temperature: float = 0.0005, sim: str = "l2",
+                   want_soft: bool = False, out: Optional[torch.Tensor] = None
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """logp[b,i,j] (and optionally softmax over text of it) from encoded text/mel.
+
+    keys_enc [B,C,T_text], queries_enc [B,C,T_mel] fp32 (channel-major, as the conv
+    encoders emit).  Rows i >= t_x[b] are masked to -inf."""
+    _lib.require_gpu()
+    k = _chk(keys_enc, "keys_enc"); q = _chk(queries_enc, "queries_enc")
+    B, C, Tx = k.shape
+    B2, C2, Ty = q.shape
+    if B != B2 or C != C2:
+        raise ValueError("keys/queries shape mismatch")
+    dev = k.device
+    if t_x is not None:
+        t_x = t_x.to(device=dev, dtype=torch.int32).contiguous()
+    if prior is not None:
+        prior = _chk(prior, "prior")
+        if tuple(prior.shape) != (B, Tx, Ty):
+            raise ValueError("prior must be [B,T_text,T_mel]")
+    logp = out if out is not None else torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev)
+    soft = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_soft else None
+    simc = {"l2": _lib.SIM_L2, "dot": _lib.SIM_DOT}[sim]
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().aligner_softattn_f32(
+            k.data_ptr(), q.data_ptr(), None if t_x is None else t_x.data_ptr(),
+            None if prior is None else prior.data_ptr(), logp.data_ptr(),
+            None if soft is None else soft.data_ptr(), B, C, Tx, Ty, float(temperature), simc, _stream(dev)))
+    return logp, soft
+
+
+@dataclass
+class AlignmentEncoderParams:
+    """Weights of the two conv stacks: lists of (weight [Cout,Cin,K], bias [Cout])."""
+    key_proj: List[Tuple[torch.Tensor, torch.Tensor]]
+    query_proj: List[Tuple[torch.Tensor, torch.Tensor]]
+    temperature: float = 0.0005
+
+    @staticmethod
+    def random(c_text: int, c_mel: int, c_att: int, device, seed: int = 0) -> "AlignmentEncoderParams":
+        g = torch.Generator(device="cpu").manual_seed(seed)
+
+        def layer(co, ci, k):
+            bound = (1.0 / (ci * k)) ** 0.5
+            w = (torch.rand((co, ci, k), generator=g) * 2 - 1) * bound
+            b = (torch.rand((co,), generator=g) * 2 - 1) * bound
+            return w.to(device), b.to(device)
+
+        return AlignmentEncoderParams(
+            key_proj=[layer(2 * c_text, c_text, 3), layer(c_att, 2 * c_text, 1)],
+            query_proj=[layer(2 * c_mel, c_mel, 3), layer(c_mel, 2 * c_mel, 1), layer(c_att, c_mel, 1)],
+        )
+
+
+def encode(x: torch.Tensor, stack: List[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
+    for n, (w, b) in enumerate(stack):
+        x = conv1d(x, w, b, relu=(n + 1 < len(stack)))
+    return x
+
+
+def alignment_encoder(text_emb: torch.Tensor, mel: torch.Tensor, params: AlignmentEncoderParams,
+                      t_x: Optional[torch.Tensor] = None, prior: Optional[torch.Tensor] = None,
+                      want_soft: bool = False):
+    """text_emb [B,C_text,T_text], mel [B,C_mel,T_mel] -> (logp [B,T_text,T_mel], soft or None)."""
+    k = encode(text_emb, params.key_proj)
+    q = encode(mel, params.query_proj)
+    return soft_attention(k, q, t_x=t_x, prior=prior, temperature=params.temperature, want_soft=want_soft)

@@ -1,0 +1,170 @@
+/*
+ * aligner_amd.h -- C ABI of libaligner_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the TTS alignment hot path of xiaozhah/Aligner:
+ *   monotonic_align.maximum_path(value, mask)      reference __init__.py:6-21
+ *   monotonic_align.core.maximum_path_c(...)       reference core.pyx:38-45
+ *   (per-utterance DP maximum_path_each)           reference core.pyx:7-35
+ * plus the soft-attention front end that produces `value` (build-defined spec,
+ * SURVEY.md 7.4; the reference snapshot only links the paper, README.md:50).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in any signature.
+ *     `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - every *_dev pointer is device memory on the current HIP device; tensors
+ *     are C-contiguous, [B, Tx, Ty] with the mel axis (Ty) contiguous, exactly
+ *     the layout the reference's memoryviews demand (core.pyx:9,40).
+ *   - all device entry points are asynchronous on `stream`, never allocate,
+ *     never synchronise, and are hipGraph-capturable.
+ *   - return 0 on success or a negative ALIGNER_E* code; aligner_last_error()
+ *     returns a thread-local message for the last failure on this thread.
+ *   - the library contains NO CPU implementation of the path: without a GPU the
+ *     device entry points fail with ALIGNER_EHIP.
+ */
+#ifndef ALIGNER_AMD_H
+#define ALIGNER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ALIGNER_ABI_VERSION 1
+
+/* error codes */
+#define ALIGNER_OK       0
+#define ALIGNER_EINVAL (-22) /* null pointer / bad shape / bad dtype / bad flag */
+#define ALIGNER_EDOM   (-33) /* shape outside what the kernels support          */
+#define ALIGNER_ENOSPC (-28) /* workspace too small                             */
+#define ALIGNER_EHIP    (-5) /* HIP runtime failure (message has the detail)    */
+
+/* element types for mask / path buffers */
+#define ALIGNER_DT_F32  0
+#define ALIGNER_DT_F16  1
+#define ALIGNER_DT_BF16 2
+#define ALIGNER_DT_F64  3
+#define ALIGNER_DT_I32  4
+#define ALIGNER_DT_U8   5   /* also torch.bool */
+#define ALIGNER_DT_I64  6
+
+/* flags for aligner_maxpath_* */
+#define ALIGNER_F_STRICT_MASK   1  /* multiply value by mask element-wise first
+                                      (__init__.py:11) instead of using the mask
+                                      for lengths only.  Needed only for masks
+                                      that are not 0/1 prefix rectangles.      */
+#define ALIGNER_F_COMPAT_TXGTTY 2  /* t_x > t_y: reproduce the reference's
+                                      result (row t_x-1 all ones) instead of
+                                      reporting ALIGNER_ST_BAD_LENGTHS         */
+#define ALIGNER_F_FORCE_GENERIC 4  /* use the generic (barrier-per-frame) kernel */
+
+/* bits of the device status word (aligner_maxpath_read_status) */
+#define ALIGNER_ST_BAD_LENGTHS  1  /* some utterance had t_x < 1 or t_x > t_y
+                                      (undefined behaviour in the reference,
+                                      core.pyx:15,33-34); its path is all zero */
+#define ALIGNER_ST_CLAMPED      2  /* some t_x > Tx or t_y > Ty was clamped     */
+#define ALIGNER_ST_INTERNAL     4  /* internal consistency check failed         */
+
+int         aligner_abi_version(void);
+const char *aligner_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int         aligner_device_count(void);
+
+/* ---- monotonic alignment search ---------------------------------------- */
+
+/* Bytes of device workspace aligner_maxpath_f32 needs for this shape. */
+size_t aligner_maxpath_workspace_bytes(int B, int Tx, int Ty);
+
+/* Replaces __init__.py:18-19: t_x[b] = sum_x mask[b,x,0], t_y[b] = sum_y mask[b,0,y]
+ * (float sum truncated to int32, like ndarray.astype(np.int32)). */
+int aligner_lengths_from_mask(const void *mask_dev, int mask_dtype,
+                              int B, int Tx, int Ty,
+                              int32_t *t_xs_dev, int32_t *t_ys_dev, void *stream);
+
+/*
+ * Replaces maximum_path_c (core.pyx:40-45) + the wrapper's marshalling
+ * (__init__.py:11-21) with everything resident in HBM.
+ *
+ *   value_dev   [B,Tx,Ty] fp32, NOT modified (the reference mutates its private
+ *               host copy; the caller's tensor is untouched there too).
+ *   mask_dev    optional [B,Tx,Ty] of mask_dtype (F32 or U8).  Used (a) to derive
+ *               lengths when t_xs_dev/t_ys_dev are NULL and (b) for the
+ *               element-wise multiply when ALIGNER_F_STRICT_MASK is set.
+ *   t_xs_dev,t_ys_dev  optional [B] int32 lengths; when NULL they are derived
+ *               from mask_dev into the workspace.
+ *   path_out_dev optional [B,Tx,Ty] of path_dtype (F32,F16,BF16,F64,I32,U8,I64),
+ *               fully written (zeros and ones): the reference's return value.
+ *   tok_out_dev optional [B,Ty] int32: text-token index per mel frame, -1 for
+ *               frames >= t_y.
+ *   dur_out_dev optional [B,Tx] int32: frames per token (= path.sum(2)).
+ *   max_neg_val core.pyx:40 (default -1e9 in the reference).
+ */
+int aligner_maxpath_f32(const float *value_dev,
+                        const void *mask_dev, int mask_dtype,
+                        const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                        void *path_out_dev, int path_dtype,
+                        int32_t *tok_out_dev, int32_t *dur_out_dev,
+                        void *workspace_dev, size_t workspace_bytes,
+                        int B, int Tx, int Ty,
+                        float max_neg_val, int flags, void *stream);
+
+/* The two stages of aligner_maxpath_f32 as separate launches (profiling and
+ * callers that only want durations): forward sweep + backtrack -> tok/dur, and
+ * tok -> dense 0/1 path. */
+int aligner_maxpath_forward_f32(const float *value_dev,
+                                const void *mask_dev, int mask_dtype,
+                                const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                                int32_t *tok_out_dev, int32_t *dur_out_dev,
+                                void *workspace_dev, size_t workspace_bytes,
+                                int B, int Tx, int Ty,
+                                float max_neg_val, int flags, void *stream);
+int aligner_maxpath_expand(const int32_t *tok_dev, void *path_out_dev, int path_dtype,
+                           int B, int Tx, int Ty, void *stream);
+
+/* Blocking read of the status word the last aligner_maxpath_* call on this
+ * workspace left behind (ALIGNER_ST_* bits). */
+int aligner_maxpath_read_status(const void *workspace_dev, int32_t *status_host, void *stream);
+
+/*
+ * Host-buffer form with exactly maximum_path_c's contract (core.pyx:40):
+ * paths[B,Tx,Ty] int32 receives the path (fully overwritten), values[B,Tx,Ty]
+ * fp32 is read (it is NOT turned into the running score Q),
+ * t_xs/t_ys[B] int32.  Stages through device memory it allocates and frees;
+ * blocking.  Returns ALIGNER_EDOM if any t_x < 1 or t_x > t_y.
+ */
+int aligner_maxpath_host_f32(int32_t *paths, const float *values,
+                             const int32_t *t_xs, const int32_t *t_ys,
+                             int B, int Tx, int Ty, float max_neg_val, int flags);
+
+/* ---- soft-attention front end (build-defined spec) ------- */
+
+#define ALIGNER_SIM_L2   0  /* logit = -temperature * sum_c (q - k)^2 */
+#define ALIGNER_SIM_DOT  1  /* logit = temperature * sum_c q*k        */
+
+/*
+ * logp[b,i,j] = log_softmax_i( logit[b,i,j] ) (+ log(prior[b,i,j] + 1e-8))
+ *   keys_dev    [B,C,Tx] fp32  encoded text  (channel-major, as Conv1d emits)
+ *   queries_dev [B,C,Ty] fp32  encoded mel
+ *   t_xs_dev    optional [B] int32: text rows >= t_x are excluded from the
+ *               softmax and written as -inf; NULL = all Tx rows valid.
+ *   prior_dev   optional [B,Tx,Ty] fp32
+ *   logp_out_dev [B,Tx,Ty] fp32; soft_out_dev optional [B,Tx,Ty] fp32 = exp(logp)
+ */
+int aligner_softattn_f32(const float *keys_dev, const float *queries_dev,
+                         const int32_t *t_xs_dev, const float *prior_dev,
+                         float *logp_out_dev, float *soft_out_dev,
+                         int B, int C, int Tx, int Ty,
+                         float temperature, int sim, void *stream);
+
+/* y[b,o,t] = act( bias[o] + sum_{i,k} w[o,i,k] * x[b,i,t+k-K/2] ), zero padded
+ * ("same"), K odd; the 1-D conv of the text / mel encoders. relu: 0 or 1. */
+int aligner_conv1d_f32(const float *x_dev, const float *w_dev, const float *bias_dev,
+                       float *y_dev, int B, int Cin, int Cout, int T, int K,
+                       int relu, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNER_AMD_H */

@@ -1,0 +1,100 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/aligner_amd.h declares; the product never touches the oracle
+and fails loudly without a GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "aligner_amd.h")) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aligner_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(built_lib):
+    from aligner_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 12
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/aligner_amd.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+
+
+def test_abi_version_and_errors(built_lib):
+    assert built_lib.aligner_abi_version() == 1
+    assert built_lib.aligner_maxpath_workspace_bytes(64, 200, 1000) > 64 * 32 * 256 * 4
+    assert built_lib.aligner_maxpath_workspace_bytes(1, 0, 5) == 0
+    # argument validation happens before any HIP call
+    rc = built_lib.aligner_maxpath_expand(None, None, 0, 1, 1, 1, None)
+    assert rc == -22 and b"null" in built_lib.aligner_last_error()
+    rc = built_lib.aligner_softattn_f32(1, 1, None, None, 1, None, 1, 300, 4, 4, 1.0, 0, None)
+    assert rc == -33
+
+
+def test_product_fails_loudly_without_gpu(built_lib):
+    if built_lib.aligner_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    import aligner_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        aligner_amd.maximum_path(torch.zeros(1, 2, 3), torch.ones(1, 2, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        aligner_amd.maximum_path_c(np.zeros((1, 2, 3), np.int32), np.zeros((1, 2, 3), np.float32),
+                                   np.array([2], np.int32), np.array([3], np.int32))
+
+
+def test_wrapper_argument_checks_mirror_the_reference(built_lib):
+    """Same rejections as the Cython glue (core.c:27882-27913, 27843), raised before any GPU work."""
+    import aligner_amd
+    v = torch.zeros(2, 3, 4)
+    with pytest.raises(ValueError, match="not C-contiguous"):
+        aligner_amd.maximum_path(v.transpose(1, 2), torch.ones(2, 4, 3))
+    with pytest.raises(ValueError, match="dimensions"):
+        aligner_amd.maximum_path(v[0], torch.ones(3, 4))
+    p = np.zeros((1, 2, 3), np.int32)
+    val = np.zeros((1, 2, 3), np.float32)
+    t = np.array([2], np.int32)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        aligner_amd.maximum_path_c(p, val.astype(np.float64), t, t)
+    with pytest.raises(ValueError, match="dimensions"):
+        aligner_amd.maximum_path_c(p[0], val[0], t, t)
+    ro = val.copy()
+    ro.setflags(write=False)
+    with pytest.raises(ValueError, match="read-only"):
+        aligner_amd.maximum_path_c(p, ro, t, t)
+
+
+def test_dropin_import_paths(built_lib):
+    import aligner_amd
+    aligner_amd.install_dropin()
+    from monotonic_align import maximum_path                       # reference __init__.py:6
+    from monotonic_align.monotonic_align.core import maximum_path_c  # reference __init__.py:3
+    assert maximum_path is aligner_amd.maximum_path
+    assert maximum_path_c is aligner_amd.maximum_path_c
+
+
+def test_product_never_imports_the_oracle():
+    """aligner_amd/, bench.py's product legs and the C sources must not reference oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "aligner_amd")):
+        if os.sep + "lib" in base:
+            continue
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                with open(os.path.join(base, fn)) as f:
+                    txt = f.read()
+                if re.search(r"\boracle\b", txt) and fn != "__init__.py":
+                    # the word may only appear in comments that say the oracle is NOT used
+                    for line in txt.splitlines():
+                        if re.search(r"^\s*(from|import)\s+.*oracle", line) or "maxpath_oracle" in line \
+                                or "libmaxpath_oracle" in line:
+                            bad.append((fn, line.strip()))
+    assert not bad, bad
