@@ -1,0 +1,235 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle, the
+golden vectors made by the real reference, and size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from aligner_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _oracle_path(value, tx, ty, neg=-1e9):
+    from oracle import maxpath_oracle as O
+    v = np.ascontiguousarray(value, dtype=np.float32).copy()
+    p = np.zeros(v.shape, np.int32)
+    O.maximum_path_c(p, v, np.ascontiguousarray(tx, np.int32), np.ascontiguousarray(ty, np.int32), neg)
+    return p
+
+
+def _hip(value, tx, ty, dev, **kw):
+    import aligner_amd
+    res = aligner_amd.align(torch.from_numpy(np.ascontiguousarray(value, np.float32)).to(dev),
+                            torch.from_numpy(np.asarray(tx, np.int32)).to(dev),
+                            torch.from_numpy(np.asarray(ty, np.int32)).to(dev),
+                            path_dtype=torch.int32, want_tok=True, want_durations=True, **kw)
+    torch.cuda.synchronize()
+    return res.path.cpu().numpy(), res.tok.cpu().numpy(), res.durations.cpu().numpy()
+
+
+def _check_consistency(path, tok, dur, tx, ty):
+    B, Tx, Ty = path.shape
+    assert np.array_equal(dur, path.sum(2))
+    for b in range(B):
+        assert np.all(tok[b, ty[b]:] == -1)
+        if ty[b] > 0:
+            assert np.array_equal(path[b].argmax(0)[:ty[b]], tok[b, :ty[b]])
+
+
+@pytest.mark.parametrize("generic", [False, True])
+def test_kats_bit_exact(kats, dev, generic):
+    import aligner_amd
+    for c in kats:
+        p, tok, dur = _hip(c["value"], c["tx"], c["ty"], dev, max_neg_val=c["neg"], force_generic=generic)
+        assert np.array_equal(p, c["path"].astype(np.int32)), c["tag"]
+        _check_consistency(p, tok, dur, c["tx"], c["ty"])
+    assert aligner_amd.read_status(dev) == 0
+
+
+def _config(tag):
+    if tag.startswith("C1"):
+        v = synth.synth_value(*synth.CONFIGS["C1"])
+        if tag == "C1-fixed":
+            return v, np.full(4, 32, np.int32), np.full(4, 128, np.int32)
+        return v, np.array([32, 20, 7, 1], np.int32), np.array([128, 100, 50, 9], np.int32)
+    if tag.startswith("C2"):
+        v = synth.synth_value(*synth.CONFIGS["C2"])
+        if tag == "C2-fixed":
+            return v, np.full(64, 200, np.int32), np.full(64, 1000, np.int32)
+        return (v,) + synth.synth_lengths(64, 200, 500, 1000, 2)
+    if tag.startswith("C4"):
+        return synth.c4_shard(int(tag[-1]))
+    v = synth.synth_value(*synth.CONFIGS["C5"])
+    return v, np.full(8, 500, np.int32), np.full(8, 4000, np.int32)
+
+
+@pytest.mark.parametrize("tag", ["C1-fixed", "C1-varlen", "C2-fixed", "C2-varlen", "C4-shard0", "C4-shard5",
+                                 "C5-longform"])
+def test_baseline_configs_match_reference_hashes(appendix_a, dev, tag):
+    """Full-size BASELINE.json configs: sha256 of the int32 path and of the durations
+    equal the values captured from the real reference (tests/golden/appendix_a.json)."""
+    rec, _ = appendix_a
+    v, tx, ty = _config(tag)
+    p, tok, dur = _hip(v, tx, ty, dev)
+    assert synth.sha256_of(p) == rec[tag]["path_sha256"]
+    assert synth.sha256_of(dur.astype(np.int32)) == rec[tag]["dur_sha256"]
+    _check_consistency(p, tok, dur, tx, ty)
+
+
+def test_generic_kernel_agrees_on_c2_varlen(appendix_a, dev):
+    rec, _ = appendix_a
+    v, tx, ty = _config("C2-varlen")
+    p, _, dur = _hip(v, tx, ty, dev, force_generic=True)
+    assert synth.sha256_of(p) == rec["C2-varlen"]["path_sha256"]
+
+
+def test_random_shapes_vs_oracle(dev):
+    rng = np.random.default_rng(1234)
+    for it in range(40):
+        B = int(rng.integers(1, 6))
+        Tx = int(rng.integers(1, 300))
+        Ty = int(rng.integers(Tx, Tx + 400))
+        kind = it % 4
+        if kind == 0:
+            v = rng.standard_normal((B, Tx, Ty))
+        elif kind == 1:
+            v = rng.integers(-2, 3, (B, Tx, Ty))              # heavy ties
+        elif kind == 2:
+            v = -rng.random((B, Tx, Ty)) * 20
+        else:
+            v = rng.standard_normal((B, Tx, Ty))
+            v[rng.random(v.shape) < 0.03] = -np.inf
+            v[rng.random(v.shape) < 0.01] = np.nan
+            v[rng.random(v.shape) < 0.01] = np.inf
+        v = v.astype(np.float32)
+        ty = rng.integers(1, Ty + 1, B).astype(np.int32)
+        tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
+        want = _oracle_path(v, tx, ty)
+        for generic in (False, True):
+            p, tok, dur = _hip(v, tx, ty, dev, force_generic=generic)
+            assert np.array_equal(p, want), (it, generic, B, Tx, Ty)
+            _check_consistency(p, tok, dur, tx, ty)
+
+
+def test_wide_text_uses_generic_path(dev):
+    """Tx > 512 is outside the pipelined kernel; the generic kernel must take over."""
+    rng = np.random.default_rng(9)
+    v = rng.standard_normal((2, 700, 900)).astype(np.float32)
+    tx = np.array([700, 513], np.int32)
+    ty = np.array([900, 640], np.int32)
+    p, tok, dur = _hip(v, tx, ty, dev)
+    assert np.array_equal(p, _oracle_path(v, tx, ty))
+
+
+def test_path_invariants_full_size(dev):
+    """Size-independent properties at the headline size on gaussian scores (no fixture)."""
+    g = torch.Generator(device="cpu").manual_seed(3)
+    v = torch.randn(64, 200, 1000, generator=g).numpy()
+    tx, ty = synth.synth_lengths(64, 200, 500, 1000, 7)
+    p, tok, dur = _hip(v, tx, ty, dev)
+    for b in range(64):
+        t = tok[b, :ty[b]]
+        assert t[0] == 0 and t[-1] == tx[b] - 1
+        d = np.diff(t)
+        assert np.all((d == 0) | (d == 1))                     # monotone, one row at a time
+        assert np.all(dur[b, :tx[b]] >= 1) and dur[b].sum() == ty[b]
+        assert p[b, tx[b]:, :].sum() == 0 and p[b, :, ty[b]:].sum() == 0
+    assert np.all(p.sum(1)[np.arange(1000)[None, :] < ty[:, None]] == 1)
+    # the chosen path's score is the DP optimum: compare with the oracle's path score
+    want = _oracle_path(v, tx, ty)
+    assert np.array_equal(p, want)
+
+
+def test_strict_mask_and_wrapper_semantics(golden_dir, dev):
+    """maximum_path(value, mask): dtype/device contract of __init__.py:6-21 on GPU tensors,
+    against outputs of the reference wrapper (tests/golden/wrapper_cases.npz)."""
+    import aligner_amd
+    z = np.load(os.path.join(golden_dir, "wrapper_cases.npz"))
+    val, mask = torch.from_numpy(z["value"]).to(dev), torch.from_numpy(z["mask"]).to(dev)
+    for name, dt in (("f32", torch.float32), ("f16", torch.float16), ("f64", torch.float64)):
+        vin = val.to(dt).requires_grad_(True)
+        r = aligner_amd.maximum_path(vin, mask.to(dt))
+        assert r.dtype == dt and r.device == vin.device and not r.requires_grad
+        assert np.array_equal(r.float().cpu().numpy().astype(np.int8), z[f"path_{name}"])
+    r = aligner_amd.maximum_path(val, mask.bool())
+    assert r.dtype == torch.float32
+    assert np.array_equal(r.cpu().numpy().astype(np.int8), z["path_boolmask"])
+    # interior zeros in the mask change the scores (strict multiply, __init__.py:11)
+    r = aligner_amd.maximum_path(val, torch.from_numpy(z["mask_holes"]).to(dev))
+    assert np.array_equal(r.cpu().numpy().astype(np.int8), z["path_holes"])
+    # garbage in the masked-out region is ignored, with and without the multiply
+    dirty = torch.from_numpy(z["value_dirty"]).to(dev)
+    for prefix in (False, True):
+        r = aligner_amd.maximum_path(dirty, mask, mask_is_prefix=prefix)
+        assert np.array_equal(r.cpu().numpy().astype(np.int8), z["path_dirty"])
+    # bf16 (extension: the reference raises TypeError): same path as the fp32 upcast
+    r = aligner_amd.maximum_path(val.bfloat16(), mask.bfloat16())
+    want = aligner_amd.maximum_path(val.bfloat16().float(), mask)
+    assert r.dtype == torch.bfloat16 and torch.equal(r.float(), want)
+    # caller's tensors untouched
+    assert torch.equal(val.cpu(), torch.from_numpy(z["value"]))
+    # CPU tensors are staged through the GPU and come back on the CPU
+    r = aligner_amd.maximum_path(torch.from_numpy(z["value"]), torch.from_numpy(z["mask"]))
+    assert r.device.type == "cpu" and np.array_equal(r.numpy().astype(np.int8), z["path_f32"])
+
+
+def test_maximum_path_c_numpy_boundary(kats, dev):
+    """core.pyx:40 signature on host buffers, through aligner_maxpath_host_f32."""
+    import aligner_amd
+    for c in kats[:20]:
+        p = np.zeros(c["value"].shape, np.int32)
+        v = c["value"].copy()
+        aligner_amd.maximum_path_c(p, v, c["tx"].copy(), c["ty"].copy(), c["neg"])
+        assert np.array_equal(p, c["path"].astype(np.int32)), c["tag"]
+    with pytest.raises(ValueError):
+        aligner_amd.maximum_path_c(np.zeros((1, 4, 3), np.int32), np.zeros((1, 4, 3), np.float32),
+                                   np.array([4], np.int32), np.array([3], np.int32))
+
+
+def test_degenerate_lengths(dev):
+    """t_y == 0 -> empty path; t_x > t_y -> the reference's all-last-row result (compat) or a
+    status bit; t_x == 0 -> status bit, zero path (the reference writes out of bounds)."""
+    import aligner_amd
+    rng = np.random.default_rng(2)
+    v = torch.from_numpy(rng.standard_normal((4, 6, 9)).astype(np.float32)).to(dev)
+    tx = torch.tensor([3, 4, 0, 2], dtype=torch.int32, device=dev)
+    ty = torch.tensor([0, 3, 5, 9], dtype=torch.int32, device=dev)
+    r = aligner_amd.align(v, tx, ty, path_dtype=torch.int32, want_tok=True, compat_tx_gt_ty=True)
+    torch.cuda.synchronize()
+    p = r.path.cpu().numpy()
+    assert p[0].sum() == 0
+    assert p[1].sum() == 3 and np.all(p[1, 3, :3] == 1)         # row t_x-1 all ones
+    assert p[2].sum() == 0
+    assert aligner_amd.read_status(dev) & 1
+    want = _oracle_path(v[3:].cpu().numpy(), np.array([2]), np.array([9]))
+    assert np.array_equal(p[3], want[0])
+    r = aligner_amd.align(v, tx, ty, path_dtype=torch.int32)
+    assert r.path[1].sum().item() == 0 and (aligner_amd.read_status(dev) & 1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.int32,
+                                torch.uint8, torch.int64])
+def test_expand_dtypes(dev, dt):
+    import aligner_amd
+    v = synth.synth_value(3, 17, 50, 99)
+    tx = np.array([17, 5, 9], np.int32)
+    ty = np.array([50, 33, 9], np.int32)
+    want = _oracle_path(v, tx, ty)
+    r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
+                          path_dtype=dt)
+    assert r.path.dtype == dt
+    assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), want)
+    # odd Ty exercises the unaligned (scalar) load/store paths
+    v = synth.synth_value(2, 9, 37, 5)
+    r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.tensor([9, 3], dtype=torch.int32, device=dev),
+                          torch.tensor([37, 20], dtype=torch.int32, device=dev), path_dtype=dt)
+    assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), _oracle_path(v, [9, 3], [37, 20]))

@@ -1,0 +1,109 @@
+"""GPU tests of the soft-attention front end against oracle/softattn_oracle.py
+(fp32 torch on CPU).  Tolerance 1e-4 absolute on log-probabilities, the figure
+BASELINE.json's north_star states; parity is UNPINNED (source absent from the
+reference snapshot, see the oracle's header)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _cmp(got, want, tol=TOL):
+    got = got.cpu()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(got), fin)
+    assert torch.equal(got[~fin], want[~fin])
+    return (got[fin] - want[fin]).abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,Tx,Ty,sim", [(2, 80, 50, 130, "l2"), (3, 80, 200, 333, "l2"), (2, 16, 7, 40, "l2"),
+                                           (2, 80, 224, 129, "dot"), (2, 96, 100, 260, "l2"), (1, 80, 300, 257, "l2"),
+                                           (2, 80, 500, 700, "l2"), (1, 200, 130, 64, "l2")])
+def test_logp_matches_oracle(dev, B, C, Tx, Ty, sim):
+    import aligner_amd
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(B * 1000 + Tx)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    t_x[0] = Tx
+    temp = 0.0005 if sim == "l2" else 0.11
+    want, want_soft = S.soft_attention(k, q, t_x=t_x, temperature=temp, sim=sim)
+    got, soft = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev), temperature=temp, sim=sim,
+                                           want_soft=True)
+    torch.cuda.synchronize()
+    assert _cmp(got, want) < TOL
+    assert (soft.cpu() - want_soft).abs().max().item() < TOL
+    # columns are normalised over the valid text rows
+    assert torch.allclose(soft.sum(1).cpu(), torch.ones(B, Ty), atol=1e-4)
+
+
+def test_prior_and_sharp_temperature(dev):
+    import aligner_amd
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(5)
+    B, C, Tx, Ty = 2, 80, 60, 200
+    k = torch.randn(B, C, Tx, generator=g) * 3
+    q = torch.randn(B, C, Ty, generator=g) * 3
+    prior = torch.rand(B, Tx, Ty, generator=g)
+    t_x = torch.tensor([60, 41], dtype=torch.int32)
+    for temp in (0.0005, 0.05):
+        want, want_soft = S.soft_attention(k, q, t_x=t_x, prior=prior, temperature=temp)
+        got, soft = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev), prior=prior.to(dev),
+                                               temperature=temp, want_soft=True)
+        torch.cuda.synchronize()
+        assert _cmp(got, want, 5e-4) < 5e-4 if temp > 0.01 else _cmp(got, want) < TOL
+        assert (soft.cpu() - want_soft).abs().max().item() < 2e-4
+
+
+def test_conv1d_and_full_encoder(dev):
+    import aligner_amd
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(11)
+    for (B, Ci, Co, T, K, relu) in [(2, 80, 160, 300, 3, True), (2, 160, 80, 300, 1, False), (1, 33, 70, 129, 5, True),
+                                    (2, 512, 1024, 50, 3, True)]:
+        x = torch.randn(B, Ci, T, generator=g)
+        w = torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5
+        b = torch.randn(Co, generator=g)
+        want = S.conv1d(x, w, b, relu)
+        got = aligner_amd.conv1d(x.to(dev), w.to(dev), b.to(dev), relu)
+        torch.cuda.synchronize()
+        assert (got.cpu() - want).abs().max().item() < 1e-4
+    params = aligner_amd.AlignmentEncoderParams.random(64, 80, 80, dev, seed=1)
+    text = torch.randn(2, 64, 40, generator=g)
+    mel = torch.randn(2, 80, 170, generator=g)
+    t_x = torch.tensor([40, 25], dtype=torch.int32)
+    got, _ = aligner_amd.alignment_encoder(text.to(dev), mel.to(dev), params, t_x=t_x.to(dev))
+    cpu = lambda st: [(w.cpu(), b.cpu()) for w, b in st]  # noqa: E731
+    want, _ = S.alignment_encoder(text, mel, cpu(params.key_proj), cpu(params.query_proj), t_x=t_x)
+    torch.cuda.synchronize()
+    assert _cmp(got, want) < TOL
+
+
+def test_pipeline_similarity_then_dp(dev):
+    """configs[1]: similarity + DP.  The hard path from the HIP log-probs equals the
+    oracle DP run on the same log-probs (bit-exact integer path)."""
+    import aligner_amd
+    from oracle import maxpath_oracle as O
+    g = torch.Generator().manual_seed(21)
+    B, C, Tx, Ty = 4, 80, 90, 400
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.tensor([90, 60, 33, 1], dtype=torch.int32)
+    t_y = torch.tensor([400, 311, 200, 17], dtype=torch.int32)
+    logp, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev))
+    res = aligner_amd.align(logp, t_x.to(dev), t_y.to(dev), path_dtype=torch.int32)
+    torch.cuda.synchronize()
+    v = logp.cpu().numpy().copy()
+    want = np.zeros(v.shape, np.int32)
+    O.maximum_path_c(want, v, t_x.numpy().copy(), t_y.numpy().copy())
+    assert np.array_equal(res.path.cpu().numpy(), want)
