@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
                 if (MASKMODE == 1)
                     v = v * reinterpret_cast<const float *>(p.mask)[((size_t)b * p.Tx + x) * p.Ty + y];
                 q[r] = (adv ? up : cur) + v;                       // core.pyx:30
-                bits[r] = (bits[r] << 1) | (adv ? 1u : 0u);
+                // backtrack predicate (core.pyx:34): the diagonal move is forced whatever the scores
+                bits[r] = (bits[r] << 1) | ((adv || x == y) ? 1u : 0u);
                 dst[x + 1] = q[r];
             }
         }
@@ -308,7 +309,10 @@ __device__ __forceinline__ void sweep_tile(float &q, unsigned &bits, const float
         if (DIAG) cur = (row == y0 + k) ? neg : q;              // core.pyx:19-20
         const bool adv = up > cur;                              // core.c:19384 (NaN -> keep cur)
         q = (adv ? up : cur) + comp(vv[k >> 2], k & 3);          // core.pyx:30
-        bits = (bits << 1) | (adv ? 1u : 0u);
+        // decision bit = the backtrack predicate (core.pyx:34): on the diagonal the move is
+        // forced whatever the scores are (NaN / scores below max_neg_val included)
+        const bool dec = DIAG ? (adv || row == y0 + k) : adv;
+        bits = (bits << 1) | (dec ? 1u : 0u);
         if (PUBLISH) pub[k] = q;                                // lane 63 -> ring, others -> scratch
     }
 }

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the alignment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): per GPU one batch [B=64, T_text=200,
+T_mel=1000] fp32 -- soft-attention log-likelihood matrix from encoded text/mel
+(the "similarity GEMM") followed by the monotonic alignment search (forward sweep +
+backtrack + dense 0/1 path + durations).  A step is one pass over one batch with
+all inputs already resident in HBM.  With N > 1 every rank aligns its own batch
+(weak scaling; utterances are independent, reference core.pyx:44-45) and the int32
+duration vectors are all-gathered over RCCL in buckets on a side stream.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with two
+extra objects: `roofline` (dominant kernel, timed with HIP events on the launch
+stream) and `cpu_baseline` (the reference / its C restatement on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from aligner_amd import _lib, synth  # noqa: E402
+
+B, C_ATT, TX, TY = 64, 80, 200, 1000
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+class Step:
+    """One pass of the hot path through the C ABI with preallocated buffers."""
+
+    def __init__(self, dev: torch.device, seed: int, use_graph: bool):
+        self.dev = dev
+        self.lib = _lib.load()
+        g = torch.Generator().manual_seed(seed)
+        self.keys = torch.randn(B, C_ATT, TX, generator=g).to(dev)       # encoded text  [B,C,Tx]
+        self.queries = torch.randn(B, C_ATT, TY, generator=g).to(dev)    # encoded mel   [B,C,Ty]
+        self.t_x = torch.full((B,), TX, dtype=torch.int32, device=dev)
+        self.t_y = torch.full((B,), TY, dtype=torch.int32, device=dev)
+        self.logp = torch.empty((B, TX, TY), dtype=torch.float32, device=dev)
+        self.path = torch.empty((B, TX, TY), dtype=torch.float32, device=dev)
+        self.tok = torch.empty((B, TY), dtype=torch.int32, device=dev)
+        self.dur = torch.empty((B, TX), dtype=torch.int32, device=dev)
+        nws = self.lib.aligner_maxpath_workspace_bytes(B, TX, TY)
+        self.ws = torch.zeros(nws + 256, dtype=torch.uint8, device=dev)
+        self.graph = None
+        self.use_graph = use_graph
+
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def softattn(self):
+        _lib.check(self.lib.aligner_softattn_f32(self.keys.data_ptr(), self.queries.data_ptr(), self.t_x.data_ptr(),
+                                                 None, self.logp.data_ptr(), None, B, C_ATT, TX, TY, 0.0005,
+                                                 _lib.SIM_L2, self.stream()))
+
+    def forward(self):
+        _lib.check(self.lib.aligner_maxpath_forward_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(),
+                                                        self.t_y.data_ptr(), self.tok.data_ptr(), self.dur.data_ptr(),
+                                                        self.ws.data_ptr(), self.ws.numel(), B, TX, TY, -1e9, 0,
+                                                        self.stream()))
+
+    def expand(self):
+        _lib.check(self.lib.aligner_maxpath_expand(self.tok.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
+                                                   self.stream()))
+
+    def eager(self):
+        self.softattn()
+        self.forward()
+        self.expand()
+
+    def capture(self):
+        """Capture the three launches of a step into a HIP graph (launch-bound otherwise)."""
+        if not self.use_graph:
+            return
+        try:
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                self.eager()
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.eager()
+            self.graph = g
+        except Exception as e:  # noqa: BLE001  (fall back to eager launches, say so)
+            print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); using eager launches",
+                  file=sys.stderr)
+            self.graph = None
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.eager()
+
+
+def event_time_us(fn, iters: int, dev) -> float:
+    """Average duration of `fn` (one launch) over `iters` back-to-back launches, HIP
+    events recorded on the stream the kernel is launched on."""
+    fn()
+    torch.cuda.synchronize(dev)
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize(dev)
+    return s.elapsed_time(e) / iters * 1e3
+
+
+def cpu_baseline(seconds: float = 12.0):
+    """The reference's maximum_path_c on the host, 1 thread (the reference ships
+    serial: setup.py passes no -fopenmp), on the same [64,200,1000] workload shape."""
+    from oracle import maxpath_oracle as O
+    value = synth.synth_value(*synth.CONFIGS["C2"])
+    tx = np.full(B, TX, np.int32)
+    ty = np.full(B, TY, np.int32)
+    ref = None
+    try:
+        ref = O.load_ref()
+    except Exception:  # noqa: BLE001
+        ref = None
+    kind = "reference" if ref is not None else "port"
+    fn = ref.maximum_path_c if ref is not None else O.maximum_path_c
+    paths = np.zeros(value.shape, np.int32)
+    work = value.copy()
+    fn(paths, work, tx, ty)                               # warm-up
+    reps, spent = 0, 0.0
+    while spent < seconds and reps < 2000:
+        np.copyto(work, value)                            # fresh scores, outside the timer
+        paths.fill(0)
+        t0 = time.perf_counter()
+        fn(paths, work, tx, ty)
+        spent += time.perf_counter() - t0
+        reps += 1
+    ups = B * reps / spent
+    return {"value": round(ups, 1), "unit": "utterances/s", "cores": 1, "kind": kind,
+            "sample": f"maximum_path_c core on [64,200,1000] fp32 scores, {reps} batches in {spent:.1f}s "
+                      f"({spent / reps * 1e3:.1f} ms/batch), host has {os.cpu_count()} logical cores",
+            "frames_per_s": round(ups * TY, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
+    ap.add_argument("--gather-every", type=int, default=16, help="steps per duration all-gather bucket (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if args.gpus > 1 or world > 1:
+        import torch.distributed as dist
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _lib.require_gpu()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    step = Step(dev, seed=1234 + rank, use_graph=not args.no_graph)
+    step.eager()
+    torch.cuda.synchronize(dev)
+    step.capture()
+
+    # duration gather (N>1): double-buffered buckets of `gather_every` steps, all-gathered over
+    # RCCL on a side stream so the exchange overlaps the next bucket's compute
+    comm_stream = torch.cuda.Stream(dev) if dist is not None else None
+    buckets = gathered = None
+    done = [None, None]
+    if dist is not None:
+        buckets = [torch.empty((args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
+
+    def run(nsteps: int):
+        ge = args.gather_every
+        for i in range(nsteps):
+            step()
+            if dist is not None:
+                bi, slot = (i // ge) % 2, i % ge
+                cur = torch.cuda.current_stream(dev)
+                if slot == 0 and done[bi] is not None:
+                    cur.wait_event(done[bi])               # bucket bi's previous gather has read it
+                buckets[bi][slot].copy_(step.dur, non_blocking=True)
+                if slot == ge - 1 or i == nsteps - 1:
+                    comm_stream.wait_stream(cur)
+                    with torch.cuda.stream(comm_stream):
+                        dist.all_gather_into_tensor(gathered[bi], buckets[bi])
+                        ev = torch.cuda.Event()
+                        ev.record(comm_stream)
+                    done[bi] = ev
+        if dist is not None:
+            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+
+    run(args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
+    assert int(step.dur.sum().item()) == B * TY and bool((step.tok[:, -1] == TX - 1).all())
+
+    if rank == 0:
+        n = max(world, 1)
+        ups = n * B * args.steps / elapsed
+        # ---- per-kernel timing with HIP events on the launch stream (second pass, same buffers) ----
+        it = 50
+        t_sim = event_time_us(step.softattn, it, dev)
+        t_fwd = event_time_us(step.forward, it, dev)
+        t_exp = event_time_us(step.expand, it, dev)
+        cells = B * TX * TY
+        kernels = {
+            "softattn_kernel": {"us": t_sim, "bytes": 4 * B * C_ATT * (TX + TY) + 4 * cells},
+            "maxpath_pipelined_kernel": {"us": t_fwd, "bytes": 4 * cells + 4 * B * (TX + TY)},
+            "expand_kernel": {"us": t_exp, "bytes": 4 * cells + 4 * B * TY},
+        }
+        dom = max(kernels, key=lambda k: kernels[k]["us"])
+        ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel_us": round(kernels[dom]["us"], 2), "algorithmic_bytes": kernels[dom]["bytes"],
+                    "all_kernels": {k: {"us": round(v["us"], 2),
+                                        "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)}
+                                    for k, v in kernels.items()}}
+        out = {
+            "metric": "aligned utterances/sec + frames/sec, [B=64,T_text=200,T_mel=1000]",
+            "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * TY, 1),
+            "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: similarity (L2, C=80) + monotonic alignment search, "
+                                   "[B=64,T_text=200,T_mel=1000] fp32 per GPU, dense fp32 path + int32 durations out",
+                       "batch_per_gpu": B, "t_text": TX, "t_mel": TY, "c_att": C_ATT,
+                       "launch": "hipGraph" if step.graph is not None else "eager",
+                       "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
+                                                               f"{args.gather_every} steps" if n > 1 else "")},
+            "roofline": roofline,
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_1thread"] = round(ups / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

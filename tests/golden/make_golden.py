@@ -102,6 +102,16 @@ def small_kats(ref):
         ty = rng.integers(1, Ty + 1, B)
         tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty])
         add(f"ragged_{i}", val, tx, ty)
+    # the forced diagonal move (core.pyx:34 `index == y`) must not depend on the scores:
+    # NaN / -inf on and next to the diagonal, and running scores below max_neg_val
+    for i, (tx, ty) in enumerate([(40, 60), (70, 90), (130, 150)]):
+        v = rng.standard_normal((tx, ty)).astype(np.float32)
+        v[rng.random(v.shape) < 0.08] = np.nan
+        v[rng.random(v.shape) < 0.08] = -np.inf
+        add(f"nan_on_diagonal_{i}", v, tx, ty)
+        add(f"below_neg_{i}", np.full((tx, ty), -6e8, np.float32) + rng.integers(0, 3, (tx, ty)).astype(np.float32),
+            tx, ty)
+        add(f"all_nan_{i}", np.full((tx, ty), np.nan, np.float32), tx, ty)
     out = {"n": np.int32(len(cases)), "tags": np.array([c["tag"] for c in cases])}
     for i, c in enumerate(cases):
         for k in ("value", "tx", "ty", "path", "q", "neg"):
