@@ -9,11 +9,12 @@
 //  * One workgroup per utterance (grid = batch), like the reference's prange.
 //  * The recurrence Q[x,y] = max(Q[x,y-1], Q[x-1,y-1]) + value[x,y] only couples
 //    a mel frame to the previous one, so a frame is one parallel step: text rows
-//    live on lanes (one row per lane, 64 rows per wave), the running column Q
-//    stays in a VGPR and the "row above" operand is a DPP wave-shift -- never LDS.
+//    live on lanes (63 rows per wave + one ghost lane that replays the row above),
+//    the running column Q stays in a VGPR and the "row above" operand is a DPP
+//    wave-shift fused into v_max_f32 -- never LDS.
 //  * Waves of a workgroup form a systolic pipeline over 32-frame tiles: in phase
-//    p wave w sweeps tile p-w and receives the boundary row of wave w-1 for that
-//    tile through a small LDS ring; one s_barrier per phase.
+//    p wave w sweeps tile p-w; the last row of wave w-1 reaches wave w's ghost
+//    lane through a 128-byte LDS ring slot per tile; one s_barrier per phase.
 //  * The score tensor is row-major with the mel axis contiguous, so a lane-per-
 //    row frame read is strided.  Dedicated loader waves (one per compute wave)
 //    stream it with coalesced 16-byte loads, DEPTH tiles in flight in registers,
@@ -22,27 +23,34 @@
 //  * Q is never stored.  Each cell leaves one decision bit
 //        dec = (x == y) | (Q[x-1,y-1] > Q[x,y-1])
 //    which is exactly the reference's backtrack predicate (core.pyx:34); 32
-//    frames make one word per lane.  The backtrack walks text rows (not frames):
-//    for row x ending at frame e the start is the highest set bit <= e, found by
-//    one ballot over the row's words (lane = tile).
+//    frames make one word per lane, kept in LDS when the utterance fits.  The
+//    backtrack walks text rows (not frames): row x ending at frame e starts at the
+//    highest set bit <= e of its own bit string.
+//  * Finite scores take a hand-scheduled sweep built on v_max_f32 (4 VALU issues per
+//    frame).  v_max differs from the reference's `(a > b) ? a : b` only when a NaN
+//    is involved, and a NaN can only arise from a non-finite input, so the loader
+//    waves watch for non-finite scores and the utterance is redone with the exact
+//    compare/select sweep if one is seen.
 //
 // Only cells inside the reference's band (core.pyx:18) influence the result;
 // cells outside it are either skipped (whole tiles) or computed and ignored --
 // they are provably never read by an in-band cell.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 #include <cstring>
 
 #include "aligner_amd.h"
 #include "common.h"
+#include "maxpath_sweep_asm.inc"
 
 namespace aligner {
 
 constexpr int TC       = 32;  // frames per tile == decision bits per word
 constexpr int TILE_LD  = 36;  // dwords per LDS tile row: 32 + 4 pad -> 16B-slot stride 9 (odd)
 constexpr int RING_T   = 4;   // boundary ring depth in tiles
-constexpr int DUMMY_W  = 96;  // per-wave scratch words for the off-lane boundary stores
+constexpr int RPW      = 63;  // text rows per compute wave (lane 0 is the ghost lane)
 constexpr int WS_HDR_BYTES = 256;
 
 enum Mode { MODE_NORMAL = 0, MODE_EMPTY = 1, MODE_COMPAT = 2 };
@@ -50,21 +58,38 @@ enum Mode { MODE_NORMAL = 0, MODE_EMPTY = 1, MODE_COMPAT = 2 };
 // LDS-qualified float: keeps per-lane selected addresses as ds_* instructions
 // (a generic pointer would turn them into flat_* accesses).
 typedef __attribute__((address_space(3))) float lds_float;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;    // 16-byte aligned: ds_read_b128
 
 struct MaxpathParams {
     const float *value;
     const void  *mask;      // strict-mask operand (nullable)
     const int   *t_xs;
     const int   *t_ys;
-    int         *tok;       // [B,Ty] (never null inside the kernels)
+    int         *starts;    // [B,Tx+1] first frame of every token (workspace)
+    int         *tok;       // [B,Ty] nullable
     int         *dur;       // [B,Tx] nullable
-    unsigned    *bits;      // [B,NT,ROWS] decision words
+    unsigned    *bits;      // [B,NT,ROWS] decision words in global memory
     int         *status;
     int B, Tx, Ty, NT, ROWS;
-    int WT;                 // tiles per backtrack window (<= 64)
+    int WT;                 // tiles per backtrack window when the words live in global memory
+    int bits_in_lds;        // pipelined kernel: decision words stay in LDS
+    int lds_bits_off;       // byte offset of that LDS region
+    int force_exact;        // skip the v_max sweep (non-finite max_neg_val)
     float neg;
     int flags;
+    unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable)
 };
+
+// Development aid: lane 0 of every wave drops a shader-clock stamp (slot 6/7 the
+// 100 MHz wall clock at entry/exit) when a stamp buffer was installed with
+// aligner_debug_set_stamps().  One uniform branch per stamp when disabled.
+#define ALIGNER_STAMP(k)                                                                        \
+    do {                                                                                        \
+        if (p.stamps && (threadIdx.x & 63) == 0)                                                \
+            p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (k)] =                \
+                ((k) == 6 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();   \
+    } while (0)
 
 // --------------------------------------------------------------------------
 // small device helpers
@@ -114,90 +139,210 @@ __device__ __forceinline__ bool tile_in_band(int t, int r0, int nrows, int tx, i
     return (TC * t + TC - 1 >= y_lo) && (TC * t <= y_hi);
 }
 
-// Outputs for the degenerate modes (whole block, uniform).
-__device__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty) {
-    for (int y = threadIdx.x; y < p.Ty; y += blockDim.x)
-        p.tok[(size_t)b * p.Ty + y] = (mode == MODE_COMPAT && y < ty) ? (tx - 1) : -1;
+// Token starts -> the caller's outputs.  starts[x] = first frame of token x for
+// x < t_x and t_y for t_x <= x <= Tx, so durations are plain differences and a
+// frame's token is found by bisection.
+__device__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, const int *startsL) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
-        for (int x = threadIdx.x; x < p.Tx; x += blockDim.x)
-            p.dur[(size_t)b * p.Tx + x] = (mode == MODE_COMPAT && x == tx - 1) ? ty : 0;
+        for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
+    if (p.tok)
+        for (int y = tid; y < p.Ty; y += nthreads) {
+            int t = -1;
+            if (y < ty) {
+                int lo = 0, hi = tx - 1;              // last x with starts[x] <= y
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (startsL[mid] <= y) lo = mid; else hi = mid - 1;
+                }
+                t = lo;
+            }
+            p.tok[(size_t)b * p.Ty + y] = t;
+        }
+}
+
+// Outputs for the degenerate modes (whole block, uniform): no ones at all, or the
+// reference's t_x > t_y result (row t_x-1 owns every frame).
+__device__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty, int *startsL) {
+    for (int x = threadIdx.x; x <= p.Tx; x += blockDim.x)
+        startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
+    __syncthreads();
+    // bisection over tx rows would name row 0; the compat answer is row tx-1 for every frame
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
+    if (p.dur)
+        for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
+    if (p.tok)
+        for (int y = tid; y < p.Ty; y += nthreads)
+            p.tok[(size_t)b * p.Ty + y] = (mode == MODE_COMPAT && y < ty) ? (tx - 1) : -1;
 }
 
 // --------------------------------------------------------------------------
 // Backtrack over decision words (shared by both forward kernels).
 //
-// LDS overlay (valid once the forward sweep is done):
-//   win  [WT][RP]   decision words of the current window, RP = ROWS+1 (odd-ish
-//                   stride: lane=tile reads of one row are conflict-free)
-//   tokL [Ty]       token index per frame
-//   durL [ROWS]     frames per token
-// Windows are visited from the last tile to the first; inside a window wave 0
-// walks rows downwards.  State (x = current row, e = its last frame) is
-// wave-uniform.
+// Word (tile t, row x) holds the decisions of text row x for frames 32t..32t+31,
+// frame 32t+c at bit 31-c.  Wave 0 walks rows from t_x-1 down: row x ending at
+// frame e starts at the highest set bit <= e of its own bit string (the move at
+// that frame is the reference's `index -= 1`, core.pyx:34-35).  Lane j holds the
+// row's word of tile jb+j (one coalesced LDS read per row, prefetched two rows
+// ahead); the walk state (x, e) lives in SGPRs.  Common case -- the start lies in
+// the word that contains e -- is one v_readlane plus scalar bit ops; otherwise a
+// ballot over the row's earlier words.
+//
+// LDS overlay once the forward sweep is done: startsL at offset 0, then (words in
+// global memory only) a window of WT tiles x (ROWS+1) words.
 // --------------------------------------------------------------------------
-__device__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty,
-                                    unsigned char *smem) {
+// One row of the single-window backtrack with everything static: wr[K] holds row (64c+K)'s
+// words (lane = tile).  ~12 scalar/vector issues in the common case, no LDS, no loop.
+template <int K>
+__device__ __forceinline__ void walk_row_static(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
+                                                int lane, int *status) {
+    const int x = xbase + K;
+    if (x <= xtop && x >= 1) {                                   // uniform
+        const unsigned w = wr[K];
+        const int je = e >> 5;
+        const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, je);
+        const unsigned mw = word & (0xFFFFFFFFu << ((~e) & (TC - 1)));
+        int s;
+        if (mw != 0u) {
+            s = (e | (TC - 1)) - __builtin_ctz(mw);
+        } else {
+            const unsigned long long bal = __ballot(lane < je && w != 0u);
+            if (bal != 0ull) {
+                const int js = 63 - __builtin_clzll(bal);
+                const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w, js);
+                s = ((js << 5) | (TC - 1)) - __builtin_ctz(wsel);
+            } else {                                             // cannot happen: the diagonal bit is always set
+                s = x;
+                if (lane == 0) atomicOr(status, ALIGNER_ST_INTERNAL);
+            }
+        }
+        s = __builtin_amdgcn_readfirstlane(s);
+        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(startv) : "s"(s), "n"(K));   // startv[lane K] = s
+        e = __builtin_amdgcn_readfirstlane(s - 1);
+    }
+}
+
+template <int K>
+struct WalkChunk {
+    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
+                                               int lane, int *status) {
+        walk_row_static<K>(wr, xbase, xtop, e, startv, lane, status);
+        WalkChunk<K - 1>::run(wr, xbase, xtop, e, startv, lane, status);
+    }
+};
+template <>
+struct WalkChunk<-1> {
+    static __device__ __forceinline__ void run(const unsigned (&)[64], int, int, int &, int &, int, int *) {}
+};
+
+__device__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthreads = blockDim.x;
     const int RP = p.ROWS + 1;
-    unsigned *win = reinterpret_cast<unsigned *>(smem);
-    int *tokL = reinterpret_cast<int *>(win + (size_t)p.WT * RP);
-    int *durL = tokL + p.Ty;
+    int *startsL = reinterpret_cast<int *>(smem);
+    const int starts_words = ((p.Tx + 1 + 63) / 64) * 64 + 64;
+    unsigned *win = reinterpret_cast<unsigned *>(smem) + starts_words;
+    const bool in_lds = p.bits_in_lds != 0;
+    if (in_lds) win = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);
 
     const int ntb = (ty + TC - 1) / TC;            // tiles this utterance uses
-    const int rows_used = ((tx + 63) / 64) * 64;   // rows whose words exist
+    const int rows_used = ((tx + 63) / 64) * 64;
     const unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS;
+    const int WT = in_lds ? ntb : p.WT;
 
-    int x = tx - 1;   // core.pyx:15
-    int e = ty - 1;
+    // Walk state lives in SGPRs: every update goes through readfirstlane so the loop is
+    // scalar control flow (a VGPR-carried loop costs an exec-mask dance per branch).
+    const bool walker = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
+    int x = __builtin_amdgcn_readfirstlane(tx - 1);   // core.pyx:15
+    int e = __builtin_amdgcn_readfirstlane(ty - 1);
+    int startv = 0;   // starts of rows 64c..64c+63 of the chunk being walked, one per lane
 
-    for (int jhi = ntb; jhi > 0; jhi -= p.WT) {
-        const int jb = (jhi - p.WT > 0) ? (jhi - p.WT) : 0;
-        const int ntw = jhi - jb;
-        __syncthreads();                           // previous window fully consumed
-        for (int idx = tid; idx < ntw * rows_used; idx += nthreads) {
-            const int j = idx / rows_used, r = idx - j * rows_used;
-            win[j * RP + r] = gbits[(size_t)(jb + j) * p.ROWS + r];
+    const bool single = ntb <= WT;                     // every tile of the utterance in one window
+    if (single) {
+        if (!in_lds) {
+            __syncthreads();
+            for (int idx = tid; idx < ntb * rows_used; idx += nthreads) {
+                const int j = idx / rows_used, r = idx - j * rows_used;
+                win[j * RP + r] = gbits[(size_t)j * p.ROWS + r];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid < 64) {
-            const int col0 = (jb + lane) * TC;
-            unsigned wn = 0;
-            if (x >= 1 && lane < ntw) wn = win[lane * RP + x];
+        ALIGNER_STAMP(2);
+        if (walker) {
+            const unsigned *wrow = win + (lane < ntb ? lane : 0) * RP;
+            for (int c = x >> 6; c >= 0; --c) {
+                unsigned wr[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) wr[k] = wrow[64 * c + k];      // 64 rows x (lane = tile)
+                WalkChunk<63>::run(wr, 64 * c, x, e, startv, lane, p.status);
+                if (c == 0) startv = (lane == 0) ? 0 : startv;              // row 0 starts at frame 0
+                startsL[64 * c + lane] = startv;
+            }
+            x = 0;
+        }
+    }
+    for (int jhi = single ? 0 : ntb; jhi > 0; jhi -= WT) {
+        const int jb = (jhi - WT > 0) ? (jhi - WT) : 0;
+        const int ntw = jhi - jb;
+        if (!in_lds) {
+            __syncthreads();                           // previous window fully consumed
+            for (int idx = tid; idx < ntw * rows_used; idx += nthreads) {
+                const int j = idx / rows_used, r = idx - j * rows_used;
+                win[j * RP + r] = gbits[(size_t)(jb + j) * p.ROWS + r];
+            }
+            __syncthreads();
+        }
+        ALIGNER_STAMP(2);
+        if (walker) {
+            // lanes past the window read tile 0's words; they can never be selected (lane < jr <= ntw)
+            const unsigned *wrow = win + (lane < ntw ? lane : 0) * RP;
+            unsigned w0 = (x >= 1) ? wrow[x] : 0u;              // words of row x
+            unsigned w1 = (x >= 2) ? wrow[x - 1] : 0u;          // row x-1 (prefetch)
             while (x >= 1) {
-                const unsigned w = wn;
-                if (x >= 2 && lane < ntw) wn = win[lane * RP + (x - 1)];   // prefetch next row
-                const int lim = e - col0;          // frames 0..lim of my tile are <= e
-                unsigned m;
-                if (lim >= TC - 1)      m = w;
-                else if (lim < 0)       m = 0u;
-                else                    m = w & (0xFFFFFFFFu << (TC - 1 - lim));
-                if (lane >= ntw) m = 0u;
-                const unsigned long long bal = __ballot(m != 0u);
-                if (bal == 0ull) break;            // row x starts in an earlier window
-                const int js = 63 - __builtin_clzll(bal);
-                const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)m, js);
-                const int s = (jb + js) * TC + (TC - 1) - __builtin_ctz(word);
-                // row x owns frames [s, e]   (core.pyx:33-35: path[index,y]=1 until the move)
-                if (lane == 0) durL[x] = e - s + 1;
-                for (int y = s + lane; y <= e; y += 64) tokL[y] = x;
-                e = s - 1;
-                x -= 1;
+                const unsigned w2 = (x >= 3) ? wrow[x - 2] : 0u;    // row x-2: two rows of LDS latency cover
+                int jr = (e >> 5) - jb;                             // window-relative tile of frame e
+                if (jr < 0) break;                                  // row x continues in an earlier window
+                unsigned mw = 0u;
+                if (jr < ntw) {
+                    const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w0, jr);
+                    mw = word & (0xFFFFFFFFu << ((~e) & (TC - 1)));
+                } else {
+                    jr = ntw;                                       // e lies past this window: every word qualifies
+                }
+                int s;
+                if (mw != 0u) {
+                    s = (((jb + jr) << 5) | (TC - 1)) - __builtin_ctz(mw);
+                } else {
+                    const unsigned long long bal = __ballot(lane < jr && w0 != 0u);
+                    if (bal == 0ull) break;                         // start lies in an earlier window
+                    const int js = 63 - __builtin_clzll(bal);
+                    const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w0, js);
+                    s = (((jb + js) << 5) | (TC - 1)) - __builtin_ctz(wsel);
+                }
+                s = __builtin_amdgcn_readfirstlane(s);
+                // row x owns frames [s, e]  (core.pyx:33-35)
+                startv = (lane == (x & 63)) ? s : startv;
+                if ((x & 63) == 0) startsL[x + lane] = startv;      // chunk complete: one LDS store
+                e = __builtin_amdgcn_readfirstlane(s - 1);
+                x = __builtin_amdgcn_readfirstlane(x - 1);
+                w0 = w1;
+                w1 = w2;
             }
         }
     }
-    if (tid < 64) {
-        // x == 0 here for every valid input (forced diagonal, core.pyx:34): row 0 takes the rest.
+    ALIGNER_STAMP(3);
+    if (walker && !single) {
+        // x == 0 here for every valid input (forced diagonal, core.pyx:34): row 0 starts at frame 0.
         if (x != 0 && lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
-        if (lane == 0) durL[0] = e + 1;
-        for (int y = lane; y <= e; y += 64) tokL[y] = 0;
+        startv = (lane == 0) ? 0 : startv;
+        startsL[lane] = startv;
     }
     __syncthreads();
-    for (int y = tid; y < p.Ty; y += nthreads)
-        p.tok[(size_t)b * p.Ty + y] = (y < ty) ? tokL[y] : -1;
-    if (p.dur)
-        for (int r = tid; r < p.Tx; r += nthreads)
-            p.dur[(size_t)b * p.Tx + r] = (r < tx) ? durL[r] : 0;
+    for (int r = tx + tid; r <= p.Tx; r += nthreads) startsL[r] = ty;
+    __syncthreads();
+    store_outputs(p, b, tx, ty, startsL);
 }
 
 // --------------------------------------------------------------------------
@@ -211,7 +356,7 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty); return; }
+    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
 
     float *qcol = reinterpret_cast<float *>(smem);   // [2][256*R + 1], index x+1
     const int QLD = 256 * R + 1;
@@ -257,63 +402,126 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
         }
         __syncthreads();
     }
+    __threadfence_block();
+    ALIGNER_STAMP(1);
     backtrack_and_store(p, b, tx, ty, smem);
 }
 
 // --------------------------------------------------------------------------
 // Pipelined forward kernel: NW compute waves + NW loader waves.
 // --------------------------------------------------------------------------
+// 4 consecutive frames of one text row, always in bounds and never predicated: `rowoff` is
+// the element offset of a clamped row, the frame index is clamped to the row's last piece.
+// Clamped duplicates only land in cells that cannot matter (rows >= Tx, frames >= Ty) and keep
+// every load unconditional, which is what lets hipcc pipeline them with counted vmcnt waits.
 template <bool VEC, int MASKMODE>
-__device__ __forceinline__ float4 load_tile_piece(const MaxpathParams &p, size_t row_off, int col) {
-    // 4 consecutive frames of one row; frames >= Ty read as 0 and never matter.
-    const float *src = p.value + row_off + col;
+__device__ __forceinline__ float4 load_tile_piece(const float *ub, const float *mb, unsigned rowoff, int col, int Ty) {
     float4 v;
-    if (VEC && col + 4 <= p.Ty) {
-        v = *reinterpret_cast<const float4 *>(src);
+    if (VEC) {
+        const unsigned off = rowoff + (unsigned)(col < Ty - 4 ? col : Ty - 4);
+        v = *reinterpret_cast<const float4 *>(ub + off);
         if (MASKMODE == 1) {
-            const float4 m = *reinterpret_cast<const float4 *>(
-                reinterpret_cast<const float *>(p.mask) + row_off + col);
+            const float4 m = *reinterpret_cast<const float4 *>(mb + off);
             v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
         }
     } else {
         float t[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            t[i] = 0.0f;
-            if (col + i < p.Ty) {
-                t[i] = src[i];
-                if (MASKMODE == 1)
-                    t[i] *= reinterpret_cast<const float *>(p.mask)[row_off + col + i];
-            }
+            const unsigned off = rowoff + (unsigned)(col + i < Ty - 1 ? col + i : Ty - 1);
+            t[i] = ub[off];
+            if (MASKMODE == 1) t[i] *= mb[off];
         }
         v = make_float4(t[0], t[1], t[2], t[3]);
     }
     return v;
 }
 
-template <bool DIAG, bool WAVE0, bool PUBLISH>
-__device__ __forceinline__ void sweep_tile(float &q, unsigned &bits, const float4 (&vv)[8],
-                                           const float4 (&bc)[8], float bprev, int row, int y0,
-                                           float neg, lds_float *pub) {
-#pragma unroll
-    for (int k = 0; k < TC; ++k) {
-        float bnd;
-        if (WAVE0) {
-            bnd = bprev;                      // 0 at (t=0,k=0), max_neg_val otherwise
-            bprev = neg;
+__device__ __forceinline__ unsigned absbits(float f) { return __builtin_bit_cast(unsigned, f) & 0x7FFFFFFFu; }
+
+// Finite-score sweep of one tile: see maxpath_sweep_asm.inc (generated by tools/gen_sweep_asm.py).
+// DIAG: the tile contains cells with row == frame; `rrel` = row - first frame of the tile.
+template <bool PUBLISH, bool DIAG>
+__device__ __forceinline__ void sweep_tile_fast(float &q, float &m, unsigned &bits, int &coll,
+                                                const float4 (&vv)[8], int rrel, float negv) {
+    float qb, cur;
+    unsigned long long sA, sB, sM0, sM1;
+    int sk0, sk1;
+#define ALIGNER_SWEEP_OPERANDS(G)                                                                       \
+    : [qa] "+v"(q), [qb] "=&v"(qb), [m] "+v"(m), [bits] "+v"(bits), [coll] "+v"(coll), [cur] "=&v"(cur), \
+      [sA] "=&s"(sA), [sB] "=&s"(sB), [sM0] "=&s"(sM0), [sM1] "=&s"(sM1), [sk0] "=&s"(sk0),             \
+      [sk1] "=&s"(sk1)                                                                                   \
+    : [rrel] "v"(rrel), [neg] "v"(negv),                                                                 \
+      [v0] "v"(vv[G].x), [v1] "v"(vv[G].y), [v2] "v"(vv[G].z), [v3] "v"(vv[G].w),                       \
+      [v4] "v"(vv[G + 1].x), [v5] "v"(vv[G + 1].y), [v6] "v"(vv[G + 1].z), [v7] "v"(vv[G + 1].w),       \
+      [v8] "v"(vv[G + 2].x), [v9] "v"(vv[G + 2].y), [v10] "v"(vv[G + 2].z), [v11] "v"(vv[G + 2].w),     \
+      [v12] "v"(vv[G + 3].x), [v13] "v"(vv[G + 3].y), [v14] "v"(vv[G + 3].z), [v15] "v"(vv[G + 3].w)    \
+    : "vcc"
+    if (DIAG) {
+        if (PUBLISH) {
+            asm volatile(ALIGNER_SWEEP16_DIAG_PUB_0 ALIGNER_SWEEP_OPERANDS(0));
+            asm volatile(ALIGNER_SWEEP16_DIAG_PUB_16 ALIGNER_SWEEP_OPERANDS(4));
         } else {
-            bnd = (k == 0) ? bprev : comp(bc[(k - 1) >> 2], (k - 1) & 3);
+            asm volatile(ALIGNER_SWEEP16_DIAG_NOPUB_0 ALIGNER_SWEEP_OPERANDS(0));
+            asm volatile(ALIGNER_SWEEP16_DIAG_NOPUB_16 ALIGNER_SWEEP_OPERANDS(4));
         }
-        const float up = dpp_wave_shr1(bnd, q);                 // Q[x-1, y-1]
-        float cur = q;                                          // Q[x,   y-1]
-        if (DIAG) cur = (row == y0 + k) ? neg : q;              // core.pyx:19-20
-        const bool adv = up > cur;                              // core.c:19384 (NaN -> keep cur)
-        q = (adv ? up : cur) + comp(vv[k >> 2], k & 3);          // core.pyx:30
-        // decision bit = the backtrack predicate (core.pyx:34): on the diagonal the move is
-        // forced whatever the scores are (NaN / scores below max_neg_val included)
-        const bool dec = DIAG ? (adv || row == y0 + k) : adv;
-        bits = (bits << 1) | (dec ? 1u : 0u);
-        if (PUBLISH) pub[k] = q;                                // lane 63 -> ring, others -> scratch
+        // the diagonal move is forced whatever the scores (core.pyx:34): frame c <-> bit 31-c
+        if (rrel >= 0 && rrel < TC) bits |= 0x80000000u >> rrel;
+    } else {
+        if (PUBLISH) {
+            asm volatile(ALIGNER_SWEEP16_PUB_0 ALIGNER_SWEEP_OPERANDS(0));
+            asm volatile(ALIGNER_SWEEP16_PUB_16 ALIGNER_SWEEP_OPERANDS(4));
+        } else {
+            asm volatile(ALIGNER_SWEEP16_NOPUB_0 ALIGNER_SWEEP_OPERANDS(0));
+            asm volatile(ALIGNER_SWEEP16_NOPUB_16 ALIGNER_SWEEP_OPERANDS(4));
+        }
+    }
+#undef ALIGNER_SWEEP_OPERANDS
+}
+
+// Exact (reference select) sweep of a whole utterance inside the pipelined kernel's
+// workgroup: one text row per thread, one barrier per frame, decision words written in
+// the same (tile, row) layout so the shared backtrack reads them unchanged.  Only taken for
+// utterances whose scores contain a NaN/infinity -- correctness path, not a fast path.
+template <int MASKMODE>
+__device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem,
+                                                   unsigned *bitsL, int RPB) {
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    float *qcol = reinterpret_cast<float *>(smem);            // [2][nthreads + 1], index x+1
+    const int QLD = nthreads + 1;
+    const float *val = p.value + (size_t)b * p.Tx * p.Ty;
+    const int x = tid;                                        // tx <= 63*NW < nthreads
+    const int slot = x;
+    unsigned *gw = p.bits + (size_t)b * p.NT * p.ROWS + slot;
+    float q = p.neg;
+    unsigned bits = 0u;
+    __syncthreads();
+    if (tid == 0) qcol[0] = 0.0f;                             // core.pyx:24-25
+    __syncthreads();
+    for (int y = 0; y < ty; ++y) {
+        const float *src = qcol + (y & 1) * QLD;
+        float *dst = qcol + ((y + 1) & 1) * QLD;
+        if (x < tx) {
+            const float up = src[x];
+            const float cur = (x == y) ? p.neg : q;             // core.pyx:19-22
+            const bool adv = up > cur;                          // core.c:19384
+            float v = val[(size_t)x * p.Ty + y];
+            if (MASKMODE == 1) v *= reinterpret_cast<const float *>(p.mask)[((size_t)b * p.Tx + x) * p.Ty + y];
+            q = (adv ? up : cur) + v;                           // core.pyx:30
+            bits = (bits << 1) | ((adv || x == y) ? 1u : 0u);   // core.pyx:34
+            dst[x + 1] = q;
+        }
+        if (tid == 0) dst[0] = p.neg;                           // core.pyx:27
+        if ((y & (TC - 1)) == TC - 1 || y == ty - 1) {
+            const int t = y / TC;
+            const unsigned wv = bits << ((TC - 1) - (y & (TC - 1)));
+            if (x < tx) {
+                if (p.bits_in_lds) bitsL[t * RPB + slot] = wv;
+                else               gw[(size_t)t * p.ROWS] = wv;
+            }
+            bits = 0u;
+        }
+        __syncthreads();
     }
 }
 
@@ -325,141 +533,174 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty); return; }
+    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    ALIGNER_STAMP(0);
+    ALIGNER_STAMP(6);
 
     float *tiles = reinterpret_cast<float *>(smem);              // [NW][2][64][TILE_LD]
-    float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][TC]
-    float *dummy = ring + NW * RING_T * TC;                      // [NW][DUMMY_W]
+    float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][TC]: row 63w-1 for wave w
+    int   *flagp = reinterpret_cast<int *>(ring + NW * RING_T * TC);   // [4] non-finite score seen
+    unsigned *bitsL = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);   // [NT][ROWS+1] when in LDS
+    const int RPB = p.ROWS + 1;
     const int ntb = (ty + TC - 1) / TC;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int nw_act = (tx + RPW - 1) / RPW;                    // waves that own at least one real row
 
-    if (wave < NW) {
-        // ------------------------------ compute wave ------------------------------
-        const int w = wave;
-        const int row = 64 * w + lane;
-        const bool active = 64 * w < tx;
-        float q = p.neg;
-        unsigned bits = 0u;
-        float *mytiles = tiles + w * 2 * 64 * TILE_LD;
-        const float *myring = ring + w * RING_T * TC;
-        float *outring = ring + (w + 1 < NW ? w + 1 : w) * RING_T * TC;
-        const bool publish = (w + 1 < NW) && (64 * (w + 1) < tx);
-        unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + row;
+    // wave 0's ghost lane replays "row -1": max_neg_val for every frame (core.pyx:27)
+    for (int i = tid; i < RING_T * TC; i += NW * 128) ring[i] = p.neg;
+    if (tid == 0) flagp[0] = 0;
+    __syncthreads();
 
-        for (int i = 0; i < w + 1; ++i) __syncthreads();
-        for (int t = 0; t < ntb; ++t) {
-            if (active && tile_in_band(t, 64 * w, 64, tx, ty)) {
-                const float *tile = mytiles + (t & 1) * 64 * TILE_LD + lane * TILE_LD;
-                float4 vv[8], bc[8];
+    if (!p.force_exact) {
+        // Tiles a wave needs form one contiguous range [t_lo, t_hi] (band of rows 63w..63w+62,
+        // core.pyx:18); every wave still takes part in all ntb + NW phase barriers.
+        const int w = (wave < NW) ? wave : wave - NW;
+        const bool active = w < nw_act;
+        const int t_lo = active ? (RPW * w) / TC : 0;
+        int t_hi = active ? (ty - tx + RPW * w + RPW - 1) / TC : -1;
+        if (t_hi > ntb - 1) t_hi = ntb - 1;
+        const int ntiles = t_hi - t_lo + 1;
+        if (wave < NW) {
+            // ------------------------------ compute wave ------------------------------
+            const int row = RPW * w + lane - 1;                 // lane 0: ghost (row 63w-1)
+            const bool publish = w + 1 < nw_act;
+            float q = (w == 0 && lane == 0) ? 0.0f : p.neg;     // Q[-1,-1] = 0 (core.pyx:24-25)
+            float m = 0.0f;                                     // lane 0 stays 0 through the asm sweep
+            unsigned bits = 0u;
+            int coll = 0;
+            const float *mytiles = tiles + w * 2 * 64 * TILE_LD + lane * TILE_LD;
+            const float *myring = ring + w * RING_T * TC;
+            float *outring = ring + (publish ? w + 1 : w) * RING_T * TC;
+            unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + (row < 0 ? 0 : row);
+
+            for (int i = 0; i < t_lo + w + 1; ++i) __syncthreads();
+            for (int t = t_lo; t <= t_hi; ++t) {
+                // one ds_read_b128 per 4 frames; the padded row stride (9 x 16 B) makes the 16-lane
+                // groups of a b128 read hit 16 different 16-byte slots: conflict-free
+                const lds_f32x4 *src = (const lds_f32x4 *)((lane == 0) ? (myring + (t & (RING_T - 1)) * TC)
+                                                                         : (mytiles + (t & 1) * 64 * TILE_LD));
+                float4 vv[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) vv[g] = *reinterpret_cast<const float4 *>(tile + 4 * g);
-                float bprev;
-                if (w == 0) {
-                    bprev = (t == 0) ? 0.0f : p.neg;                         // core.pyx:24-27
-                } else {
-                    const float *rs = myring + (t & (RING_T - 1)) * TC;
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) bc[g] = *reinterpret_cast<const float4 *>(rs + 4 * g);
-                    bprev = myring[((t - 1) & (RING_T - 1)) * TC + (TC - 1)];
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 r = src[g];
+                    vv[g] = make_float4(r.x, r.y, r.z, r.w);
                 }
-                lds_float *pub = (lds_float *)((lane == 63) ? (outring + (t & (RING_T - 1)) * TC)
-                                                            : (dummy + w * DUMMY_W + lane));
                 const int y0 = t * TC;
-                const bool diag = (y0 <= 64 * w + 63) && (y0 + TC - 1 >= 64 * w);
-                if (w == 0) {
-                    if (diag) { if (publish) sweep_tile<true, true, true>(q, bits, vv, bc, bprev, row, y0, p.neg, pub);
-                                else         sweep_tile<true, true, false>(q, bits, vv, bc, bprev, row, y0, p.neg, pub); }
-                    else      { if (publish) sweep_tile<false, true, true>(q, bits, vv, bc, bprev, row, y0, p.neg, pub);
-                                else         sweep_tile<false, true, false>(q, bits, vv, bc, bprev, row, y0, p.neg, pub); }
+                const bool diag = (y0 <= RPW * w + RPW - 1) && (y0 + TC - 1 >= RPW * w);
+                const int rrel = row - y0;
+                if (diag) {
+                    if (publish) sweep_tile_fast<true, true>(q, m, bits, coll, vv, rrel, p.neg);
+                    else         sweep_tile_fast<false, true>(q, m, bits, coll, vv, rrel, p.neg);
                 } else {
-                    if (diag) { if (publish) sweep_tile<true, false, true>(q, bits, vv, bc, bprev, row, y0, p.neg, pub);
-                                else         sweep_tile<true, false, false>(q, bits, vv, bc, bprev, row, y0, p.neg, pub); }
-                    else      { if (publish) sweep_tile<false, false, true>(q, bits, vv, bc, bprev, row, y0, p.neg, pub);
-                                else         sweep_tile<false, false, false>(q, bits, vv, bc, bprev, row, y0, p.neg, pub); }
+                    if (publish) sweep_tile_fast<true, false>(q, m, bits, coll, vv, rrel, p.neg);
+                    else         sweep_tile_fast<false, false>(q, m, bits, coll, vv, rrel, p.neg);
                 }
-                gbits[(size_t)t * p.ROWS] = bits;      // frame 32t+c <-> bit 31-c
+                if (publish && lane < TC) outring[(t & (RING_T - 1)) * TC + lane] = __builtin_bit_cast(float, coll);
+                if (lane != 0) {                                              // word of (tile t, text row)
+                    if (p.bits_in_lds) bitsL[t * RPB + row] = bits;           // frame 32t+c <-> bit 31-c
+                    else               gbits[(size_t)t * p.ROWS] = bits;
+                }
                 bits = 0u;
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        for (int i = 0; i < NW - 1 - w; ++i) __syncthreads();
-    } else {
-        // ------------------------------ loader wave -------------------------------
-        const int w = wave - NW;
-        const bool active = 64 * w < tx;
-        const int rr = lane >> 3, cg = lane & 7;
-        float *mytiles = tiles + w * 2 * 64 * TILE_LD;
-        size_t row_off[8];
+            for (int i = 0; i < ntb + NW - w - t_hi - 2; ++i) __syncthreads();
+        } else {
+            // ------------------------------ loader wave -------------------------------
+            if (active) {
+                const int rr = lane >> 3, cg = lane & 7;
+                float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 4 * cg;
+                const float *ub = p.value + ubase;
+                const float *mb = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + ubase : nullptr;
+                // LDS row slot 8k+rr <-> text row 63w + 8k + rr - 1 (slot 0 is the ghost lane's: never read)
+                unsigned rowoff[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            int r = 64 * w + 8 * k + rr;
-            if (r > p.Tx - 1) r = p.Tx - 1;            // rows >= Tx: any in-bounds row will do
-            row_off[k] = ubase + (size_t)r * p.Ty;
-        }
-        float4 buf[DEPTH][8];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (active && d < ntb && tile_in_band(d, 64 * w, 64, tx, ty)) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    buf[d][k] = load_tile_piece<VEC, MASKMODE>(p, row_off[k], TC * d + 4 * cg);
-            }
-        }
-        for (int i = 0; i < w; ++i) __syncthreads();
-        for (int t0 = 0; t0 < ntb; t0 += DEPTH) {
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                const int t = t0 + d;
-                if (t < ntb) {
-                    if (active && tile_in_band(t, 64 * w, 64, tx, ty)) {
-                        float *dst = mytiles + (t & 1) * 64 * TILE_LD + rr * TILE_LD + 4 * cg;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = buf[d][k];
-                    }
-                    const int tn = t + DEPTH;
-                    if (active && tn < ntb && tile_in_band(tn, 64 * w, 64, tx, ty)) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            buf[d][k] = load_tile_piece<VEC, MASKMODE>(p, row_off[k], TC * tn + 4 * cg);
-                    }
-                    __syncthreads();
+                for (int k = 0; k < 8; ++k) {
+                    // rows past the utterance's own text (padding: often -inf log-probs) are replaced
+                    // by its last row: they are never read by the DP and must not trip the finiteness scan
+                    int r = RPW * w + 8 * k + rr - 1;
+                    r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
+                    rowoff[k] = (unsigned)r * (unsigned)p.Ty;
                 }
+                unsigned nf = 0u;                           // max |bits| seen: >= 0x7F800000 <=> inf or NaN
+                float4 buf[DEPTH][8];
+                // every refill is issued unconditionally (tile index clamped to t_hi: duplicates hit
+                // L2) so the number of loads in flight at each register->LDS pass is a constant
+                auto issue = [&](float4 (&dst)[8], int t) {
+                    const int tc = t < t_hi ? t : t_hi;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        dst[k] = load_tile_piece<VEC, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
+                };
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
+                for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        const int t = t_lo + i0 + d;
+                        if (t <= t_hi) {
+                            float *dst = mytiles + (t & 1) * 64 * TILE_LD;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                float4 v = buf[d][k];
+                                if (t == ntb - 1) {                 // frames >= t_y (mel padding) never matter: zero them
+                                    const int c0 = TC * t + 4 * cg;
+                                    v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
+                                    v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
+                                }
+                                *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                const unsigned a = absbits(v.x), bb = absbits(v.y), c = absbits(v.z), dd = absbits(v.w);
+                                const unsigned ab = a > bb ? a : bb, cd = c > dd ? c : dd;
+                                const unsigned mx = ab > cd ? ab : cd;
+                                nf = nf > mx ? nf : mx;
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(buf[d], t + DEPTH);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t <= t_hi) __syncthreads();
+                    }
+                }
+                if (nf >= 0x7F800000u) flagp[0] = 1;        // benign race: every writer stores 1
+                for (int i = 0; i < ntb + NW - w - t_hi - 1; ++i) __syncthreads();
+            } else {
+                for (int i = 0; i < ntb + NW; ++i) __syncthreads();
             }
         }
-        for (int i = 0; i < NW - w; ++i) __syncthreads();
+        __syncthreads();
     }
-    // all decision words of this utterance are in global memory (same CU wrote them)
+    // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
+    // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
+    if (p.force_exact || flagp[0] != 0) exact_fallback_sweep<MASKMODE>(p, b, tx, ty, smem, bitsL, RPB);
+    // decision words: in LDS, or in global memory written by this CU
     __threadfence_block();
+    ALIGNER_STAMP(1);
     backtrack_and_store(p, b, tx, ty, smem);
+    ALIGNER_STAMP(5);
+    ALIGNER_STAMP(7);
 }
 
 // --------------------------------------------------------------------------
-// tok -> dense 0/1 path in the caller's dtype (the reference's return value,
-// __init__.py:21).  Pure streaming store.
+// starts -> dense 0/1 path in the caller's dtype (the reference's return value,
+// __init__.py:21).  Pure streaming store: path[b,x,y] = starts[x] <= y < starts[x+1].
 // --------------------------------------------------------------------------
 template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ tok, T *__restrict__ path,
+__global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ starts, T *__restrict__ path,
                                                       int Tx, int Ty, int rows_per_block, T one) {
     const int b = blockIdx.z;
     const int x0 = blockIdx.y * rows_per_block;
     const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (y0 >= Ty) return;
-    int tk[4];
-    if (VEC) {
-        const int4 v = *reinterpret_cast<const int4 *>(tok + (size_t)b * Ty + y0);
-        tk[0] = v.x; tk[1] = v.y; tk[2] = v.z; tk[3] = v.w;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) tk[i] = (y0 + i < Ty) ? tok[(size_t)b * Ty + y0 + i] : -1;
-    }
     const int x1 = (x0 + rows_per_block < Tx) ? x0 + rows_per_block : Tx;
+    const int *st = starts + (size_t)b * (Tx + 1);
     struct alignas(sizeof(T) * 4) Vec4 { T v[4]; };
+    int s = st[x0];                                       // block-uniform: scalar loads
     for (int x = x0; x < x1; ++x) {
+        const int e = st[x + 1];
         T *dst = path + ((size_t)b * Tx + x) * Ty + y0;
         Vec4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o.v[i] = (tk[i] == x) ? one : T(0);
+        for (int i = 0; i < 4; ++i) o.v[i] = (y0 + i >= s && y0 + i < e) ? one : T(0);
         if (VEC) {
             *reinterpret_cast<Vec4 *>(dst) = o;
         } else {
@@ -467,6 +708,7 @@ __global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ tok
             for (int i = 0; i < 4; ++i)
                 if (y0 + i < Ty) dst[i] = o.v[i];
         }
+        s = e;
     }
 }
 
@@ -498,19 +740,25 @@ __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
+static unsigned long long *g_debug_stamps = nullptr;
+
 struct WsLayout {
-    size_t status_off, len_off, tok_off, bits_off, total;
+    size_t status_off, len_off, starts_off, bits_off, total;
     int NT, ROWS;
 };
 
 static WsLayout ws_layout(int B, int Tx, int Ty) {
     WsLayout L;
     L.NT = (Ty + TC - 1) / TC;
-    L.ROWS = (Tx + 63) / 64 * 64;
+    // one word per text row and tile; rounded so whole waves / blocks of lanes can store
+    // without a bounds test (pipelined: 63*NW rows, generic: 256*R rows)
+    const int rows_pipe = (Tx + RPW - 1) / RPW * RPW + 1;
+    const int rows_plain = (Tx + 255) / 256 * 256;
+    L.ROWS = ((rows_pipe > rows_plain ? rows_pipe : rows_plain) + 63) / 64 * 64;
     L.status_off = 0;
     L.len_off = WS_HDR_BYTES;
-    L.tok_off = align_up(L.len_off + (size_t)2 * B * sizeof(int), 256);
-    L.bits_off = align_up(L.tok_off + (size_t)B * Ty * sizeof(int), 256);
+    L.starts_off = align_up(L.len_off + (size_t)2 * B * sizeof(int), 256);
+    L.bits_off = align_up(L.starts_off + (size_t)B * (Tx + 1) * sizeof(int), 256);
     L.total = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
     return L;
 }
@@ -532,15 +780,15 @@ static int lds_limit() {
     return lim;
 }
 
-// Backtrack overlay size for a window of WT tiles.
-static size_t walk_bytes(int WT, int ROWS, int Ty) {
-    return ((size_t)WT * (ROWS + 1) + Ty + ROWS) * 4;
-}
+static size_t starts_bytes(int Tx) { return (size_t)(((Tx + 1 + 63) / 64) * 64 + 64) * 4; }
 
-static int pick_window(int NT, int ROWS, int Ty, size_t budget) {
+// Backtrack overlay size for a window of WT tiles (decision words in global memory).
+static size_t walk_bytes(int WT, int ROWS, int Tx) { return starts_bytes(Tx) + (size_t)WT * (ROWS + 1) * 4; }
+
+static int pick_window(int NT, int ROWS, int Tx, size_t budget) {
     int WT = NT < 64 ? NT : 64;
-    while (WT > 1 && walk_bytes(WT, ROWS, Ty) > budget) --WT;
-    return walk_bytes(WT, ROWS, Ty) <= budget ? WT : 0;
+    while (WT > 1 && walk_bytes(WT, ROWS, Tx) > budget) --WT;
+    return walk_bytes(WT, ROWS, Tx) <= budget ? WT : 0;
 }
 
 template <typename K>
@@ -589,7 +837,6 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
     unsigned char *wsb = static_cast<unsigned char *>(ws);
 
-    ALIGNER_HIP_CHECK(hipMemsetAsync(wsb + L.status_off, 0, WS_HDR_BYTES, s));
     if (!t_xs || !t_ys) {
         int *lx = reinterpret_cast<int *>(wsb + L.len_off), *ly = lx + B;
         int rc = aligner_lengths_from_mask(mask, mask_dtype, B, Tx, Ty, lx, ly, s);
@@ -601,26 +848,41 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     p.value = value;
     p.mask = (flags & ALIGNER_F_STRICT_MASK) ? mask : nullptr;
     p.t_xs = t_xs; p.t_ys = t_ys;
-    p.tok = tok_out ? tok_out : reinterpret_cast<int *>(wsb + L.tok_off);
+    p.starts = reinterpret_cast<int *>(wsb + L.starts_off);
+    p.tok = tok_out;
     p.dur = dur_out;
     p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
     p.status = reinterpret_cast<int *>(wsb + L.status_off);
     p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
     p.neg = neg; p.flags = flags;
+    p.bits_in_lds = 0; p.lds_bits_off = 0;
+    p.force_exact = !(neg - neg == 0.0f);            // NaN / inf max_neg_val
+    p.stamps = g_debug_stamps;
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
     const size_t lds_max = (size_t)lds_limit();
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
                      (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
 
-    const int nw_need = (Tx + 63) / 64;
+    const int nw_need = (Tx + RPW - 1) / RPW;
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8) {
         const int NW = nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
-        const size_t fwd = (size_t)NW * (2 * 64 * TILE_LD + RING_T * TC + DUMMY_W) * 4;
-        if (fwd <= lds_max) {
-            p.WT = pick_window(L.NT, L.ROWS, Ty, lds_max);
-            if (p.WT > 0) {
-                size_t lds = walk_bytes(p.WT, L.ROWS, Ty);
-                if (lds < fwd) lds = fwd;
+        const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * TC) * 4 + 16, 16);
+        if (fwd <= lds_max && starts_bytes(Tx) <= fwd) {
+            size_t lds = 0;
+            const size_t bits_lds = (size_t)L.NT * (L.ROWS + 1) * 4;
+            if (L.NT <= 64 && fwd + bits_lds <= lds_max) {
+                p.bits_in_lds = 1;
+                p.lds_bits_off = (int)fwd;
+                p.WT = L.NT;
+                lds = fwd + bits_lds;
+            } else {
+                p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
+                if (p.WT > 0) {
+                    lds = walk_bytes(p.WT, L.ROWS, Tx);
+                    if (lds < fwd) lds = fwd;
+                }
+            }
+            if (lds) {
                 switch (NW) {
                     case 1: return launch_pipelined<1, 4>(p, vec, maskmode, lds, s);
                     case 2: return launch_pipelined<2, 4>(p, vec, maskmode, lds, s);
@@ -635,9 +897,9 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     if (R > 8) return fail(ALIGNER_EDOM, "Tx=%d exceeds the 2048 text rows the kernels support", Tx);
     const int RR = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
     const size_t fwd = (size_t)2 * (256 * RR + 1) * 4;
-    p.WT = pick_window(L.NT, L.ROWS, Ty, lds_max);
-    if (p.WT <= 0) return fail(ALIGNER_EDOM, "Ty=%d too long for the backtrack window", Ty);
-    size_t lds = walk_bytes(p.WT, L.ROWS, Ty);
+    p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
+    if (p.WT <= 0) return fail(ALIGNER_EDOM, "Tx=%d/Ty=%d too large for the backtrack window", Tx, Ty);
+    size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
     if (lds < fwd) lds = fwd;
     switch (RR) {
         case 1: return launch_generic<1>(p, maskmode, lds, s);
@@ -648,17 +910,30 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
 }
 
 template <typename T>
-static int launch_expand(const int *tok, void *path, int B, int Tx, int Ty, T one, hipStream_t s) {
+static int launch_expand(const int *starts, void *path, int B, int Tx, int Ty, T one, hipStream_t s) {
     const int rpb = 8;
     dim3 grid((Ty + 1023) / 1024, (Tx + rpb - 1) / rpb, B), block(256);
-    const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) % (sizeof(T) * 4)) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(tok) & 15) == 0);
+    const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) % (sizeof(T) * 4)) == 0);
     if (vec)
-        hipLaunchKernelGGL((expand_kernel<T, true>), grid, block, 0, s, tok, static_cast<T *>(path), Tx, Ty, rpb, one);
+        hipLaunchKernelGGL((expand_kernel<T, true>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
     else
-        hipLaunchKernelGGL((expand_kernel<T, false>), grid, block, 0, s, tok, static_cast<T *>(path), Tx, Ty, rpb, one);
+        hipLaunchKernelGGL((expand_kernel<T, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
+}
+
+static int expand_impl(const int *starts, void *path, int path_dtype, int B, int Tx, int Ty, hipStream_t s) {
+    if (B > 65535 || (Tx + 7) / 8 > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    switch (path_dtype) {
+        case ALIGNER_DT_F32: return launch_expand<float>(starts, path, B, Tx, Ty, 1.0f, s);
+        case ALIGNER_DT_F64: return launch_expand<double>(starts, path, B, Tx, Ty, 1.0, s);
+        case ALIGNER_DT_I32: return launch_expand<int32_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_I64: return launch_expand<int64_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_U8:  return launch_expand<uint8_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_F16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3C00, s);
+        case ALIGNER_DT_BF16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3F80, s);
+        default: return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    }
 }
 
 }  // namespace aligner
@@ -706,23 +981,14 @@ int aligner_maxpath_forward_f32(const float *value, const void *mask, int mask_d
                         max_neg_val, flags, static_cast<hipStream_t>(stream));
 }
 
-int aligner_maxpath_expand(const int32_t *tok, void *path, int path_dtype, int B, int Tx, int Ty,
+int aligner_maxpath_expand(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty,
                            void *stream) {
-    if (!tok || !path) return fail(ALIGNER_EINVAL, "null pointer");
+    if (!ws || !path) return fail(ALIGNER_EINVAL, "null pointer");
     if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
     if (B == 0) return ALIGNER_OK;
-    if (B > 65535 || (Tx + 7) / 8 > 65535) return fail(ALIGNER_EDOM, "grid too large");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (path_dtype) {
-        case ALIGNER_DT_F32: return launch_expand<float>(tok, path, B, Tx, Ty, 1.0f, s);
-        case ALIGNER_DT_F64: return launch_expand<double>(tok, path, B, Tx, Ty, 1.0, s);
-        case ALIGNER_DT_I32: return launch_expand<int32_t>(tok, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_I64: return launch_expand<int64_t>(tok, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_U8:  return launch_expand<uint8_t>(tok, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_F16: return launch_expand<uint16_t>(tok, path, B, Tx, Ty, 0x3C00, s);
-        case ALIGNER_DT_BF16: return launch_expand<uint16_t>(tok, path, B, Tx, Ty, 0x3F80, s);
-        default: return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
-    }
+    const WsLayout L = ws_layout(B, Tx, Ty);
+    const int *starts = reinterpret_cast<const int *>(static_cast<const unsigned char *>(ws) + L.starts_off);
+    return expand_impl(starts, path, path_dtype, B, Tx, Ty, static_cast<hipStream_t>(stream));
 }
 
 int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, const int32_t *t_xs,
@@ -734,16 +1000,18 @@ int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, co
     int rc = forward_impl(value, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
                           max_neg_val, flags, static_cast<hipStream_t>(stream));
     if (rc || !path_out || B == 0) return rc;
-    const WsLayout L = ws_layout(B, Tx, Ty);
-    const int *tok = tok_out ? tok_out
-                             : reinterpret_cast<const int *>(static_cast<unsigned char *>(ws) + L.tok_off);
-    return aligner_maxpath_expand(tok, path_out, path_dtype, B, Tx, Ty, stream);
+    return aligner_maxpath_expand(ws, path_out, path_dtype, B, Tx, Ty, stream);
 }
 
-int aligner_maxpath_read_status(const void *ws, int32_t *status_host, void *stream) {
+void aligner_debug_set_stamps(void *stamps_dev) {
+    g_debug_stamps = static_cast<unsigned long long *>(stamps_dev);
+}
+
+int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {
     if (!ws || !status_host) return fail(ALIGNER_EINVAL, "null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ALIGNER_HIP_CHECK(hipMemcpyAsync(status_host, ws, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    ALIGNER_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(int32_t), s));     // status is sticky until read
     ALIGNER_HIP_CHECK(hipStreamSynchronize(s));
     return ALIGNER_OK;
 }
@@ -770,6 +1038,7 @@ int aligner_maxpath_host_f32(int32_t *paths, const float *values, const int32_t 
     HOST_TRY(hipMalloc(&d_path, n * 4));
     HOST_TRY(hipMalloc(&d_len, (size_t)2 * B * 4));
     HOST_TRY(hipMalloc(&d_ws, wsb));
+    HOST_TRY(hipMemset(d_ws, 0, WS_HDR_BYTES));
     HOST_TRY(hipMemcpy(d_val, values, n * 4, hipMemcpyHostToDevice));
     HOST_TRY(hipMemcpy(d_len, t_xs, (size_t)B * 4, hipMemcpyHostToDevice));
     HOST_TRY(hipMemcpy(static_cast<int *>(d_len) + B, t_ys, (size_t)B * 4, hipMemcpyHostToDevice));

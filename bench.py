@@ -73,7 +73,7 @@ class Step:
                                                         self.stream()))
 
     def expand(self):
-        _lib.check(self.lib.aligner_maxpath_expand(self.tok.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
+        _lib.check(self.lib.aligner_maxpath_expand(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
                                                    self.stream()))
 
     def eager(self):

@@ -111,8 +111,8 @@ int aligner_maxpath_f32(const float *value_dev,
                         float max_neg_val, int flags, void *stream);
 
 /* The two stages of aligner_maxpath_f32 as separate launches (profiling and
- * callers that only want durations): forward sweep + backtrack -> tok/dur, and
- * tok -> dense 0/1 path. */
+ * callers that only want durations): forward sweep + backtrack -> token starts in
+ * the workspace (+ optional tok/dur), and workspace -> dense 0/1 path. */
 int aligner_maxpath_forward_f32(const float *value_dev,
                                 const void *mask_dev, int mask_dtype,
                                 const int32_t *t_xs_dev, const int32_t *t_ys_dev,
@@ -120,12 +120,17 @@ int aligner_maxpath_forward_f32(const float *value_dev,
                                 void *workspace_dev, size_t workspace_bytes,
                                 int B, int Tx, int Ty,
                                 float max_neg_val, int flags, void *stream);
-int aligner_maxpath_expand(const int32_t *tok_dev, void *path_out_dev, int path_dtype,
+int aligner_maxpath_expand(const void *workspace_dev, void *path_out_dev, int path_dtype,
                            int B, int Tx, int Ty, void *stream);
 
-/* Blocking read of the status word the last aligner_maxpath_* call on this
- * workspace left behind (ALIGNER_ST_* bits). */
-int aligner_maxpath_read_status(const void *workspace_dev, int32_t *status_host, void *stream);
+/* Blocking read-and-clear of the workspace's status word (ALIGNER_ST_* bits).  The
+ * word is sticky: kernels only OR bits into it, so the first 256 bytes of a fresh
+ * workspace must be zero (hipMemset once at allocation; no per-call memset). */
+int aligner_maxpath_read_status(void *workspace_dev, int32_t *status_host, void *stream);
+
+/* Development aid: install (or clear with NULL) a device buffer of B*16*8 uint64 that
+ * the forward kernels fill with shader-clock stamps per wave (see maxpath.hip). */
+void aligner_debug_set_stamps(void *stamps_dev);
 
 /*
  * Host-buffer form with exactly maximum_path_c's contract (core.pyx:40):

@@ -89,7 +89,7 @@ def main():
                                                    dur.data_ptr(), ws.data_ptr(), ws.numel(), B, Tx, Ty, -1e9, flags, st))
 
     def expand():
-        _lib.check(lib.aligner_maxpath_expand(tok.data_ptr(), path.data_ptr(), 0, B, Tx, Ty, st))
+        _lib.check(lib.aligner_maxpath_expand(ws.data_ptr(), path.data_ptr(), 0, B, Tx, Ty, st))
 
     print("forward pipelined us", round(ev_time(lambda: fwd(0)), 2))
     print("forward generic   us", round(ev_time(lambda: fwd(4), iters=5), 2))
