@@ -45,7 +45,8 @@ SIGNATURES = {
     "aligner_maxpath_read_status": (_i, [_vp, _vp, _vp]),
     "aligner_debug_set_stamps": (None, [_vp]),
     "aligner_maxpath_host_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
-    "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    "aligner_softattn_workspace_bytes": (_sz, [_i, _i, _i]),
+    "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
     "aligner_conv1d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -12,6 +12,8 @@ char *error_buffer() {
     return buf;
 }
 
+unsigned long long *g_debug_stamps = nullptr;
+
 int fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -27,6 +29,10 @@ extern "C" {
 int aligner_abi_version(void) { return ALIGNER_ABI_VERSION; }
 
 const char *aligner_last_error(void) { return aligner::error_buffer(); }
+
+void aligner_debug_set_stamps(void *stamps_dev) {
+    aligner::g_debug_stamps = static_cast<unsigned long long *>(stamps_dev);
+}
 
 int aligner_device_count(void) {
     int n = 0;

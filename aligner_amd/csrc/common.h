@@ -33,6 +33,9 @@ inline int dtype_size(int dt) {
     }
 }
 
+// development aid shared by the kernel files (aligner_debug_set_stamps)
+extern unsigned long long *g_debug_stamps;
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace aligner

@@ -740,7 +740,6 @@ __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
-static unsigned long long *g_debug_stamps = nullptr;
 
 struct WsLayout {
     size_t status_off, len_off, starts_off, bits_off, total;
@@ -1001,10 +1000,6 @@ int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, co
                           max_neg_val, flags, static_cast<hipStream_t>(stream));
     if (rc || !path_out || B == 0) return rc;
     return aligner_maxpath_expand(ws, path_out, path_dtype, B, Tx, Ty, stream);
-}
-
-void aligner_debug_set_stamps(void *stamps_dev) {
-    g_debug_stamps = static_cast<unsigned long long *>(stamps_dev);
 }
 
 int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {

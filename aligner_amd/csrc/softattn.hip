@@ -45,69 +45,123 @@ struct SoftAttnParams {
     const float *prior;     // nullable [B,Tx,Ty]
     float *logp;            // [B,Tx,Ty]
     float *soft;            // nullable
+    const uint4 *frag_hi;   // [B][RT][KS][64] text operand, bf16 high halves in MFMA A-fragment order
+    const uint4 *frag_lo;   // same, low halves
+    const float *knorm;     // [B][RT*32] |k_i|^2
+    int RT;                 // row tiles of 32 text rows
+    unsigned long long *stamps;   // debug (nullable): [blocks][4 waves][8] shader clock
     int B, C, Tx, Ty;
     float temperature;
     int sim;
 };
+
+constexpr int SA_WAVES = 8;                       // waves per workgroup: 8 x 32 = 256 mel frames share one staged text operand
+constexpr int SA_THREADS = SA_WAVES * 64;
+constexpr float NEG_INF_F = -__builtin_huge_valf();
+constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
 }
 
-constexpr float NEG_INF_F = -__builtin_huge_valf();
-
-// Row group -> LDS: split the text operand to bf16 hi/lo in MFMA A-fragment order
-// (A[i = lane&31][k = 8*(lane>>5)+jj] for row tile r, k-step s) and |k_i|^2.
-template <int KS, int G>
-__device__ __forceinline__ void stage_text_group(const SoftAttnParams &p, const float *Kb, int row0,
-                                                 bf16x8 *Ahi, bf16x8 *Alo, float *kn) {
+// Text operand prep (once per utterance, not once per workgroup): split K to bf16 hi/lo in
+// MFMA A-fragment order (A[i = lane&31][k = 8*(lane>>5)+jj] for row tile r, k-step s) and
+// |k_i|^2, into the workspace.  One workgroup per (row tile, utterance).
+template <int KS>
+__global__ __launch_bounds__(256) void softattn_prep_kernel(const float *__restrict__ keys, uint4 *__restrict__ frag_hi,
+                                                            uint4 *__restrict__ frag_lo, float *__restrict__ knorm,
+                                                            int C, int Tx, int RT) {
+    __shared__ float part[32][2 * KS + 1];
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < G * KS * 64; idx += 256) {
-        const int ln = idx & 63;
-        const int s = (idx >> 6) % KS;
-        const int r = (idx >> 6) / KS;
-        const int i = row0 + 32 * r + (ln & 31);
+    const int r = blockIdx.x, b = blockIdx.y;
+    const float *Kb = keys + (size_t)b * C * Tx;
+    for (int idx = tid; idx < KS * 64; idx += 256) {
+        const int ln = idx & 63, s = idx >> 6;
+        const int i = 32 * r + (ln & 31);
         const int c0 = 16 * s + 8 * (ln >> 5);
         bf16x8 h, l;
+        float sq = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             float v = 0.f;
-            if (i < p.Tx && c0 + jj < p.C) v = Kb[(size_t)(c0 + jj) * p.Tx + i];
+            if (i < Tx && c0 + jj < C) v = Kb[(size_t)(c0 + jj) * Tx + i];
+            sq += v * v;
             __bf16 hh, ll;
             split_bf16(v, hh, ll);
             h[jj] = hh;
             l[jj] = ll;
         }
+        const size_t o = ((size_t)(b * RT + r) * KS + s) * 64 + ln;
+        frag_hi[o] = __builtin_bit_cast(uint4, h);
+        frag_lo[o] = __builtin_bit_cast(uint4, l);
+        part[ln & 31][2 * s + (ln >> 5)] = sq;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * KS; ++j) acc += part[tid][j];      // fixed order: deterministic
+        knorm[(size_t)(b * RT + r) * 32 + tid] = acc;
+    }
+}
+
+// Row group -> LDS: plain 16-byte copies of the prepared fragments (+ the norms).
+template <int KS, int G>
+__device__ __forceinline__ void stage_text_group(const SoftAttnParams &p, int b, int g, uint4 *Ahi, uint4 *Alo,
+                                                 float *kn, int tx, bool l2, float s2) {
+    const int tid = threadIdx.x;
+    const int r0 = G * g;
+    const size_t base = ((size_t)(b * p.RT + r0) * KS) * 64;
+    const int nvalid = (p.RT - r0 < G ? p.RT - r0 : G) * KS * 64;      // fragments that exist
+    for (int idx = tid; idx < G * KS * 64; idx += SA_THREADS) {
+        uint4 h = make_uint4(0, 0, 0, 0), l = h;
+        if (idx < nvalid) { h = p.frag_hi[base + idx]; l = p.frag_lo[base + idx]; }
         Ahi[idx] = h;
         Alo[idx] = l;
     }
-    for (int il = tid; il < G * 32; il += 256) {
-        const int i = row0 + il;
-        float sacc = 0.f;
-        if (i < p.Tx)
-            for (int c = 0; c < p.C; ++c) {
-                const float v = Kb[(size_t)c * p.Tx + i];
-                sacc += v * v;
-            }
-        kn[il] = sacc;
+    // per-row additive term of the base-2 logit: s2*|k_i|^2 (L2) or 0 (dot); -inf masks rows >= t_x
+    for (int il = tid; il < G * 32; il += SA_THREADS) {
+        const int i = r0 * 32 + il;
+        float v = NEG_INF_F;
+        if (i < tx) v = l2 ? s2 * p.knorm[(size_t)(b * p.RT + r0) * 32 + il] : 0.f;
+        kn[il] = v;
     }
+}
+
+// dot products of one 32-row tile with this wave's 32 frames: 3x bf16 MFMA per k-step
+// (hi*hi + hi*lo + lo*hi).  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+template <int KS>
+__device__ __forceinline__ f32x16 tile_dot(const uint4 *Ahi_r, const uint4 *Alo_r, const bf16x8 (&bhi)[KS],
+                                           const bf16x8 (&blo)[KS], int lane) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi_r[s * 64 + lane]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, Alo_r[s * 64 + lane]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[s], acc, 0, 0, 0);
+    }
+    return acc;
 }
 
 // logits of one 32-row tile for this lane's column: 3x bf16 MFMA + distance/scale/mask.
 // C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 template <int KS>
-__device__ __forceinline__ void tile_logits(float (&lg)[16], const bf16x8 *Ahi_r, const bf16x8 *Alo_r,
+__device__ __forceinline__ void tile_logits(float (&lg)[16], const uint4 *Ahi_r, const uint4 *Alo_r,
                                             const bf16x8 (&bhi)[KS], const bf16x8 (&blo)[KS],
-                                            const float *kn_r, float qn, float scale, bool l2,
+                                            const float *kn_r, float qn, float s2, bool l2,
                                             int i_lane0, int tx, int lane) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const bf16x8 ah = Ahi_r[s * 64 + lane];
-        const bf16x8 al = Alo_r[s * 64 + lane];
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, Ahi_r[s * 64 + lane]);
+        const bf16x8 al = __builtin_bit_cast(bf16x8, Alo_r[s * 64 + lane]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[s], acc, 0, 0, 0);
@@ -117,8 +171,9 @@ __device__ __forceinline__ void tile_logits(float (&lg)[16], const bf16x8 *Ahi_r
     for (int e = 0; e < 16; ++e) {
         const int il = (e & 3) + 8 * (e >> 2) + half4;
         const float d = acc[e];
-        const float v = l2 ? scale * ((kn_r[il] + qn) - 2.0f * d) : scale * d;
-        lg[e] = (i_lane0 + (e & 3) + 8 * (e >> 2) < tx) ? v : NEG_INF_F;
+        // kn_r holds the base-2 row term (s2*|k|^2 or 0; -inf for masked rows): back to natural log
+        const float v = (l2 ? fmaf(d, -2.0f * s2, kn_r[il] + s2 * qn) : fmaf(d, s2, kn_r[il])) * LN2_F;
+        lg[e] = v;
     }
 }
 
@@ -146,72 +201,150 @@ __device__ __forceinline__ float load_mel_fragments(const SoftAttnParams &p, con
 
 // MULTI == false: all text rows fit one row group (Tx <= 32*G): logits stay in registers.
 // MULTI == true : row groups, two sweeps (running max/sum, then normalise + store).
+#define SA_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (p.stamps && (threadIdx.x & 63) == 0)                                                      \
+            p.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SA_WAVES + (threadIdx.x >> 6)) * 8 + (k)] = \
+                __builtin_amdgcn_s_memtime();                                                         \
+    } while (0)
+
 template <int KS, int G, bool MULTI>
-__global__ __launch_bounds__(256) void softattn_kernel(SoftAttnParams p) {
+__global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softattn_kernel(SoftAttnParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16x8 *Ahi = reinterpret_cast<bf16x8 *>(smem);            // [G][KS][64]
-    bf16x8 *Alo = Ahi + G * KS * 64;                           // [G][KS][64]
+    uint4 *Ahi = reinterpret_cast<uint4 *>(smem);              // [G][KS][64] bf16x8 fragments
+    uint4 *Alo = Ahi + G * KS * 64;                            // [G][KS][64]
     float *kn = reinterpret_cast<float *>(Alo + G * KS * 64);  // [G*32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
     const int b = blockIdx.y;
-    const int col = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int col = blockIdx.x * (32 * SA_WAVES) + wave * 32 + (lane & 31);
     const bool col_ok = col < p.Ty;
     int tx = p.Tx;
     if (p.t_xs) {
         tx = p.t_xs[b];
         tx = tx < 0 ? 0 : (tx > p.Tx ? p.Tx : tx);
     }
-    const float *Kb = p.keys + (size_t)b * p.C * p.Tx;
     const float *Qb = p.queries + (size_t)b * p.C * p.Ty;
     const bool l2 = (p.sim == ALIGNER_SIM_L2);
     const float scale = l2 ? -p.temperature : p.temperature;
+    const float s2 = scale * LOG2E_F;                  // logits are kept in base 2 (v_exp_f32 is exp2)
 
+    SA_STAMP(0);
+    // mel operand: issue the strided loads now, convert after the text operand is staged
+    float qraw[KS][8];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int c = 16 * s + 8 * half + jj;
+            qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+        }
+    if (!MULTI) stage_text_group<KS, G>(p, b, 0, Ahi, Alo, kn, tx, l2, s2);
     bf16x8 bhi[KS], blo[KS];
-    const float qn = load_mel_fragments<KS>(p, Qb, col, col_ok, half, bhi, blo);
+    float qn = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float v = qraw[s][jj];
+            qn += v * v;
+            __bf16 h, l;
+            split_bf16(v, h, l);
+            bhi[s][jj] = h;
+            blo[s][jj] = l;
+        }
+    qn += __shfl_xor(qn, 32);
+    SA_STAMP(1);
 
     if (!MULTI) {
-        stage_text_group<KS, G>(p, Kb, 0, Ahi, Alo, kn);
         __syncthreads();
+        SA_STAMP(2);
+        // lg = logit * log2(e) = acc*dmul + (bias[row] + qterm); bias carries the row mask (-inf)
+        const float qterm = l2 ? s2 * qn : 0.f;
+        const float dmul = l2 ? -2.0f * s2 : s2;
         float lg[G][16];
-        float m = NEG_INF_F;
+        float m = NEG_INF_F, l = 0.f;                 // running max / sum of 2^(lg - m) over this lane's rows
+        f32x16 acc = tile_dot<KS>(Ahi, Alo, bhi, blo, lane);
 #pragma unroll
         for (int r = 0; r < G; ++r) {
-            tile_logits<KS>(lg[r], Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, scale, l2,
-                            32 * r + 4 * half, tx, lane);
+            // issue the next tile's MFMAs before this tile's VALU epilogue so the two overlap
+            f32x16 acc_next;
+            if (r + 1 < G) acc_next = tile_dot<KS>(Ahi + (r + 1) * KS * 64, Alo + (r + 1) * KS * 64, bhi, blo, lane);
+            float tmax = NEG_INF_F;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) m = fmaxf(m, lg[r][e]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int gq = 0; gq < 4; ++gq) {
+                // rows 8*gq + 4*half + (0..3) of the tile: one ds_read_b128 of their bias
+                const float4 bz = *reinterpret_cast<const float4 *>(kn + 32 * r + 8 * gq + 4 * half);
+                lg[r][4 * gq + 0] = fmaf(acc[4 * gq + 0], dmul, bz.x + qterm);
+                lg[r][4 * gq + 1] = fmaf(acc[4 * gq + 1], dmul, bz.y + qterm);
+                lg[r][4 * gq + 2] = fmaf(acc[4 * gq + 2], dmul, bz.z + qterm);
+                lg[r][4 * gq + 3] = fmaf(acc[4 * gq + 3], dmul, bz.w + qterm);
+                tmax = fmaxf(fmaxf(tmax, fmaxf(lg[r][4 * gq + 0], lg[r][4 * gq + 1])),
+                             fmaxf(lg[r][4 * gq + 2], lg[r][4 * gq + 3]));
+            }
+            const float mn = fmaxf(m, tmax);
+            const float ms = (mn == NEG_INF_F) ? 0.f : mn;
+            float ts = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ts += __builtin_amdgcn_exp2f(lg[r][e] - ms);
+            l = l * __builtin_amdgcn_exp2f((m == NEG_INF_F ? ms : m) - ms) + ts;
+            m = mn;
+            if (r + 1 < G) acc = acc_next;
         }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        const float mm = (m == NEG_INF_F) ? 0.f : m;
-        float l = 0.f;
-#pragma unroll
-        for (int r = 0; r < G; ++r)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) l += __expf(lg[r][e] - mm);
-        l += __shfl_xor(l, 32);
-        const float lse = mm + __logf(l);
+        SA_STAMP(3);
+        // merge the two half-waves (rows 4*half offset) of each column
+        const float m_o = __shfl_xor(m, 32), l_o = __shfl_xor(l, 32);
+        const float m_all = fmaxf(m, m_o);
+        const float m_fin = (m_all == NEG_INF_F) ? 0.f : m_all;
+        const float l_all = (m == NEG_INF_F ? 0.f : l * __builtin_amdgcn_exp2f(m - m_fin)) +
+                            (m_o == NEG_INF_F ? 0.f : l_o * __builtin_amdgcn_exp2f(m_o - m_fin));
+        const float lse2 = m_fin + __builtin_amdgcn_logf(l_all);   // v_log_f32 = log2
+        SA_STAMP(4);
 
-        // per-lane base + wave-uniform row offsets keep the addresses out of VGPRs
+        // per-lane base + wave-uniform row offsets keep the addresses out of VGPRs; bounds tests
+        // are hoisted: the column test once per lane, the row test only for the last partial tile
         const size_t lane_off = ((size_t)b * p.Tx + 4 * half) * p.Ty + col;
         const int i_lane = 4 * half;
+        const float c0 = -lse2 * LN2_F;
         float m2 = NEG_INF_F;
+        if (col_ok) {
 #pragma unroll
-        for (int r = 0; r < G; ++r) {
+            for (int r = 0; r < G; ++r) {
+                if (32 * r >= p.Tx) break;                                   // uniform
+                const bool full = 32 * r + 32 <= p.Tx;                       // uniform
+                if (p.prior) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                const bool ok = (i_lane + iu < p.Tx) && col_ok;
-                float v = lg[r][e] - lse;
-                if (p.prior && ok) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
-                lg[r][e] = v;
-                m2 = fmaxf(m2, v);
-                if (ok) p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                        float v = fmaf(lg[r][e], LN2_F, c0);
+                        if (full || i_lane + iu < p.Tx) {
+                            v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
+                            p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                        }
+                        lg[r][e] = v;
+                        m2 = fmaxf(m2, v);
+                    }
+                } else if (full) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                        const float v = fmaf(lg[r][e], LN2_F, c0);
+                        lg[r][e] = v;
+                        p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                        const float v = fmaf(lg[r][e], LN2_F, c0);
+                        lg[r][e] = v;
+                        if (i_lane + iu < p.Tx) p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                    }
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
+        SA_STAMP(5);
         if (p.soft) {
             // softmax over text of the final log-probs (== exp(logp) when there is no prior)
             float lse2 = 0.f;
@@ -244,11 +377,11 @@ __global__ __launch_bounds__(256) void softattn_kernel(SoftAttnParams p) {
         for (int g = 0; g < NG; ++g) {
             const int row0 = 32 * G * g;
             __syncthreads();
-            stage_text_group<KS, G>(p, Kb, row0, Ahi, Alo, kn);
+            stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
             for (int r = 0; r < G; ++r) {
                 float lg[16];
-                tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, scale, l2,
+                tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
                                 row0 + 32 * r + 4 * half, tx, lane);
                 float tm = m_run;
 #pragma unroll
@@ -274,12 +407,12 @@ __global__ __launch_bounds__(256) void softattn_kernel(SoftAttnParams p) {
         for (int g = 0; g < NG; ++g) {
             const int row0 = 32 * G * g;
             __syncthreads();
-            stage_text_group<KS, G>(p, Kb, row0, Ahi, Alo, kn);
+            stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
             for (int r = 0; r < G; ++r) {
                 float lg[16];
                 const int i_lane = row0 + 32 * r + 4 * half;
-                tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, scale, l2,
+                tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
                                 i_lane, tx, lane);
                 const size_t lane_off = ((size_t)b * p.Tx + i_lane) * p.Ty + col;
 #pragma unroll
@@ -372,14 +505,33 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const float *__restrict__ x
     }
 }
 
+struct SaLayout { size_t hi_off, lo_off, kn_off, total; int RT, KS; };
+
+static SaLayout sa_layout(int B, int C, int Tx) {
+    SaLayout L;
+    L.RT = (Tx + 31) / 32;
+    const int ks = (C + 15) / 16;
+    L.KS = ks <= 5 ? 5 : ks <= 8 ? 8 : 16;
+    const size_t frag = (size_t)B * L.RT * L.KS * 64 * sizeof(uint4);
+    L.hi_off = 0;
+    L.lo_off = align_up(frag, 256);
+    L.kn_off = L.lo_off + align_up(frag, 256);
+    L.total = L.kn_off + align_up((size_t)B * L.RT * 32 * sizeof(float), 256);
+    return L;
+}
+
 template <int KS, int G, bool MULTI>
-static int launch_softattn(const SoftAttnParams &p, hipStream_t s) {
-    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(bf16x8) + (size_t)G * 32 * sizeof(float);
+static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaLayout &L, hipStream_t s) {
+    hipLaunchKernelGGL(softattn_prep_kernel<KS>, dim3(L.RT, p.B), dim3(256), 0, s, p.keys,
+                       reinterpret_cast<uint4 *>(ws + L.hi_off), reinterpret_cast<uint4 *>(ws + L.lo_off),
+                       reinterpret_cast<float *>(ws + L.kn_off), p.C, p.Tx, L.RT);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float);
     auto kern = softattn_kernel<KS, G, MULTI>;
     if (lds > 64 * 1024)
         ALIGNER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((p.Ty + 127) / 128, p.B), block(256);
+    dim3 grid((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES), p.B), block(SA_THREADS);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
@@ -391,26 +543,35 @@ using namespace aligner;
 
 extern "C" {
 
+size_t aligner_softattn_workspace_bytes(int B, int C, int Tx) {
+    if (B < 0 || C < 1 || Tx < 1) return 0;
+    return sa_layout(B, C, Tx).total;
+}
+
 int aligner_softattn_f32(const float *keys, const float *queries, const int32_t *t_xs, const float *prior,
-                         float *logp_out, float *soft_out, int B, int C, int Tx, int Ty, float temperature,
-                         int sim, void *stream) {
-    if (!keys || !queries || !logp_out) return fail(ALIGNER_EINVAL, "null pointer");
+                         float *logp_out, float *soft_out, void *workspace, size_t workspace_bytes, int B, int C,
+                         int Tx, int Ty, float temperature, int sim, void *stream) {
+    if (!keys || !queries || !logp_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
     if (B < 0 || C < 1 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d C=%d Tx=%d Ty=%d", B, C, Tx, Ty);
     if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
     if (C > 256) return fail(ALIGNER_EDOM, "C=%d exceeds 256 attention channels", C);
     if (B > 65535) return fail(ALIGNER_EDOM, "B=%d too large", B);
     if (B == 0) return ALIGNER_OK;
-    SoftAttnParams p{keys, queries, t_xs, prior, logp_out, soft_out, B, C, Tx, Ty, temperature, sim};
-    const int RT = (Tx + 31) / 32;
-    const int ks = (C + 15) / 16;
-    const int G = ks <= 8 ? 7 : 4;
-    const bool multi = RT > G;
+    const SaLayout L = sa_layout(B, C, Tx);
+    if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    SoftAttnParams p{keys, queries, t_xs, prior, logp_out, soft_out,
+                     reinterpret_cast<const uint4 *>(ws + L.hi_off), reinterpret_cast<const uint4 *>(ws + L.lo_off),
+                     reinterpret_cast<const float *>(ws + L.kn_off), L.RT, g_debug_stamps, B, C, Tx, Ty, temperature,
+                     sim};
+    const int G = L.KS <= 8 ? 7 : 4;
+    const bool multi = L.RT > G;
     if (soft_out && prior && multi)
         return fail(ALIGNER_EDOM, "soft output with a prior needs Tx <= %d", 32 * G);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (ks <= 5) return multi ? launch_softattn<5, 7, true>(p, s) : launch_softattn<5, 7, false>(p, s);
-    if (ks <= 8) return multi ? launch_softattn<8, 7, true>(p, s) : launch_softattn<8, 7, false>(p, s);
-    return multi ? launch_softattn<16, 4, true>(p, s) : launch_softattn<16, 4, false>(p, s);
+    if (L.KS == 5) return multi ? launch_softattn<5, 7, true>(p, ws, L, s) : launch_softattn<5, 7, false>(p, ws, L, s);
+    if (L.KS == 8) return multi ? launch_softattn<8, 7, true>(p, ws, L, s) : launch_softattn<8, 7, false>(p, ws, L, s);
+    return multi ? launch_softattn<16, 4, true>(p, ws, L, s) : launch_softattn<16, 4, false>(p, ws, L, s);
 }
 
 int aligner_conv1d_f32(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int Cout,

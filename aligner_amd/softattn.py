@@ -31,6 +31,17 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+_workspaces: dict = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _workspaces[device] = ws
+    return ws
+
+
 def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -76,11 +87,14 @@ def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optio
     logp = out if out is not None else torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev)
     soft = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_soft else None
     simc = {"l2": _lib.SIM_L2, "dot": _lib.SIM_DOT}[sim]
+    lib = _lib.load()
     with torch.cuda.device(dev):
-        _lib.check(_lib.load().aligner_softattn_f32(
+        ws = _workspace(dev, lib.aligner_softattn_workspace_bytes(B, C, Tx))
+        _lib.check(lib.aligner_softattn_f32(
             k.data_ptr(), q.data_ptr(), None if t_x is None else t_x.data_ptr(),
             None if prior is None else prior.data_ptr(), logp.data_ptr(),
-            None if soft is None else soft.data_ptr(), B, C, Tx, Ty, float(temperature), simc, _stream(dev)))
+            None if soft is None else soft.data_ptr(), ws.data_ptr(), ws.numel(),
+            B, C, Tx, Ty, float(temperature), simc, _stream(dev)))
     return logp, soft
 
 

@@ -55,6 +55,8 @@ class Step:
         self.dur = torch.empty((B, TX), dtype=torch.int32, device=dev)
         nws = self.lib.aligner_maxpath_workspace_bytes(B, TX, TY)
         self.ws = torch.zeros(nws + 256, dtype=torch.uint8, device=dev)
+        self.sa_ws = torch.empty(self.lib.aligner_softattn_workspace_bytes(B, C_ATT, TX) + 256, dtype=torch.uint8,
+                                 device=dev)
         self.graph = None
         self.use_graph = use_graph
 
@@ -63,7 +65,8 @@ class Step:
 
     def softattn(self):
         _lib.check(self.lib.aligner_softattn_f32(self.keys.data_ptr(), self.queries.data_ptr(), self.t_x.data_ptr(),
-                                                 None, self.logp.data_ptr(), None, B, C_ATT, TX, TY, 0.0005,
+                                                 None, self.logp.data_ptr(), None, self.sa_ws.data_ptr(),
+                                                 self.sa_ws.numel(), B, C_ATT, TX, TY, 0.0005,
                                                  _lib.SIM_L2, self.stream()))
 
     def forward(self):

@@ -155,11 +155,15 @@ int aligner_maxpath_host_f32(int32_t *paths, const float *values,
  *   t_xs_dev    optional [B] int32: text rows >= t_x are excluded from the
  *               softmax and written as -inf; NULL = all Tx rows valid.
  *   prior_dev   optional [B,Tx,Ty] fp32
- *   logp_out_dev [B,Tx,Ty] fp32; soft_out_dev optional [B,Tx,Ty] fp32 = exp(logp)
+ *   logp_out_dev [B,Tx,Ty] fp32; soft_out_dev optional [B,Tx,Ty] fp32 = softmax_i(logp)
+ *   workspace_dev  aligner_softattn_workspace_bytes(B,C,Tx) bytes: the text operand split
+ *               to bf16 halves in MFMA fragment order, prepared once per call.
  */
+size_t aligner_softattn_workspace_bytes(int B, int C, int Tx);
 int aligner_softattn_f32(const float *keys_dev, const float *queries_dev,
                          const int32_t *t_xs_dev, const float *prior_dev,
                          float *logp_out_dev, float *soft_out_dev,
+                         void *workspace_dev, size_t workspace_bytes,
                          int B, int C, int Tx, int Ty,
                          float temperature, int sim, void *stream);
 

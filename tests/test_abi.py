@@ -36,7 +36,7 @@ def test_abi_version_and_errors(built_lib):
     # argument validation happens before any HIP call
     rc = built_lib.aligner_maxpath_expand(None, None, 0, 1, 1, 1, None)
     assert rc == -22 and b"null" in built_lib.aligner_last_error()
-    rc = built_lib.aligner_softattn_f32(1, 1, None, None, 1, None, 1, 300, 4, 4, 1.0, 0, None)
+    rc = built_lib.aligner_softattn_f32(1, 1, None, None, 1, None, 1, 1 << 30, 1, 300, 4, 4, 1.0, 0, None)
     assert rc == -33
 
 
