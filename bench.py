@@ -166,6 +166,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per duration all-gather bucket (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,10 +186,18 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    step = Step(dev, seed=1234 + rank, use_graph=not args.no_graph)
-    step.eager()
+    # S independent batches in flight: step i runs on stream i % S with its own buffers, so the
+    # latency-bound DP of one batch (64 of 256 CUs) overlaps the bandwidth-bound kernels of the next
+    nstreams = max(1, args.streams)
+    steps = [Step(dev, seed=1234 + 17 * rank + 1000 * i, use_graph=not args.no_graph) for i in range(nstreams)]
+    streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
+    for st, strm in zip(steps, streams):
+        with torch.cuda.stream(strm):
+            st.eager()
     torch.cuda.synchronize(dev)
-    step.capture()
+    for st in steps:
+        st.capture()
+    step = steps[0]
 
     # duration gather (N>1): double-buffered buckets of `gather_every` steps, all-gathered over
     # RCCL on a side stream so the exchange overlaps the next bucket's compute
@@ -200,14 +210,20 @@ def main():
 
     def run(nsteps: int):
         ge = args.gather_every
+        main = torch.cuda.current_stream(dev)
+        for strm in streams:
+            strm.wait_stream(main)
         for i in range(nsteps):
-            step()
+            k = i % nstreams
+            with torch.cuda.stream(streams[k]):
+                steps[k]()
             if dist is not None:
+                main.wait_stream(streams[k])
                 bi, slot = (i // ge) % 2, i % ge
-                cur = torch.cuda.current_stream(dev)
+                cur = main
                 if slot == 0 and done[bi] is not None:
                     cur.wait_event(done[bi])               # bucket bi's previous gather has read it
-                buckets[bi][slot].copy_(step.dur, non_blocking=True)
+                buckets[bi][slot].copy_(steps[k].dur, non_blocking=True)
                 if slot == ge - 1 or i == nsteps - 1:
                     comm_stream.wait_stream(cur)
                     with torch.cuda.stream(comm_stream):
@@ -215,8 +231,10 @@ def main():
                         ev = torch.cuda.Event()
                         ev.record(comm_stream)
                     done[bi] = ev
+        for strm in streams:
+            main.wait_stream(strm)
         if dist is not None:
-            torch.cuda.current_stream(dev).wait_stream(comm_stream)
+            main.wait_stream(comm_stream)
 
     run(args.warmup)
     torch.cuda.synchronize(dev)
@@ -236,7 +254,8 @@ def main():
         elapsed = float(t.item())
 
     # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
-    assert int(step.dur.sum().item()) == B * TY and bool((step.tok[:, -1] == TX - 1).all())
+    for st in steps:
+        assert int(st.dur.sum().item()) == B * TY and bool((st.tok[:, -1] == TX - 1).all())
 
     if rank == 0:
         n = max(world, 1)
@@ -271,6 +290,7 @@ def main():
                                    "[B=64,T_text=200,T_mel=1000] fp32 per GPU, dense fp32 path + int32 durations out",
                        "batch_per_gpu": B, "t_text": TX, "t_mel": TY, "c_att": C_ATT,
                        "launch": "hipGraph" if step.graph is not None else "eager",
+                       "batches_in_flight": nstreams,
                        "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
                                                                f"{args.gather_every} steps" if n > 1 else "")},
             "roofline": roofline,
