@@ -233,3 +233,22 @@ def test_expand_dtypes(dev, dt):
     r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.tensor([9, 3], dtype=torch.int32, device=dev),
                           torch.tensor([37, 20], dtype=torch.int32, device=dev), path_dtype=dt)
     assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), _oracle_path(v, [9, 3], [37, 20]))
+
+
+def test_sharded_product_path_single_rank(appendix_a, dev):
+    """The multi-GPU entry point with the real HIP align_fn on a 1-rank RCCL group:
+    durations of C4 shard 0 equal the reference's (tests/golden/appendix_a_arrays.npz)."""
+    import torch.distributed as dist
+    from aligner_amd import sharded
+    _, arrays = appendix_a
+    v, tx, ty = synth.c4_shard(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        vd = torch.from_numpy(v).to(dev)
+        got = sharded.sharded_align(lambda idx: vd[torch.as_tensor(idx, device=dev)], tx, ty, v.shape[1], device=dev)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(got.cpu().numpy(), arrays["c4_s0_dur"].astype(np.int32))
