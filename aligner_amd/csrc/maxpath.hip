@@ -681,6 +681,281 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
 }
 
 // --------------------------------------------------------------------------
+// Halo-lane forward kernel (Tx <= 256, NT <= 64, everything LDS-resident): the fast path.
+//
+// Same systolic tile pipeline as above, but a wave owns only 32 text rows (lanes 32..63) and
+// its 32 low lanes RECOMPUTE the 32 rows above it instead of receiving the boundary row through
+// LDS every frame.  A recomputed row is wrong once the missing row above the halo has propagated
+// down to it, i.e. halo lane h is wrong after frame h of a tile -- so lane 31 stays right for the
+// whole 32-frame tile, and the halo is resynchronised from the upper wave's saved registers once
+// per tile (one ds_write_b32 + one ds_read_b32 per wave and tile; nothing per frame).  The inner
+// loop is 5 VALU issues per frame for every wave (ALIGNER_HALO16_*).
+//
+// The sweep also tracks, per cell, the row its best path occupied just before the tile's first
+// frame (B, one v_cndmask_b32_dpp per frame).  At the end of a tile that is the tile's backtrack
+// transition  T_t: row at frame 32t+31 -> row at frame 32t-1,  stored as one byte per row.  The
+// backtrack then is: (1) a short serial walk through the last (partial) tile, (2) NT-2 dependent
+// table look-ups giving the path's row at every tile boundary, (3) all tiles resolved in
+// parallel, one lane per tile (each lane walks the <= 32 rows that start inside its tile).
+// --------------------------------------------------------------------------
+constexpr int HB = 32;          // real rows (and halo rows) per wave
+constexpr int HSLOTS = 3;       // LDS slots per band tile / saved-register ring
+
+struct HaloLds {                 // byte offsets inside dynamic LDS
+    int tiles, qsave, zero, flag, bits, tbl, total;
+};
+
+__host__ __device__ inline HaloLds halo_lds_layout(int nw, int NT, int ROWS) {
+    HaloLds L;
+    int o = 0;
+    L.tiles = o; o += nw * HSLOTS * HB * TILE_LD * 4;
+    L.qsave = o; o += nw * HSLOTS * 64 * 4;
+    L.zero = o;  o += TILE_LD * 4 + 16;
+    L.flag = o;  o += 16;
+    L.bits = o;  o += NT * (ROWS + 1) * 4;
+    L.tbl = o;   o += ((NT * ROWS + 15) / 16) * 16;
+    L.total = o;
+    return L;
+}
+
+template <bool DIAG>
+__device__ __forceinline__ void sweep_tile_halo(float &q, float &m, unsigned &nbits, int &B, const float4 (&vv)[8],
+                                                int rrel, float negv) {
+    float qb, cur;
+    unsigned long long sM0, sM1;
+#define ALIGNER_HALO_OPERANDS(G)                                                                         \
+    : [qa] "+v"(q), [qb] "=&v"(qb), [m] "+v"(m), [bits] "+v"(nbits), [B] "+v"(B), [cur] "=&v"(cur),      \
+      [sM0] "=&s"(sM0), [sM1] "=&s"(sM1)                                                                 \
+    : [rrel] "v"(rrel), [neg] "v"(negv),                                                                 \
+      [v0] "v"(vv[G].x), [v1] "v"(vv[G].y), [v2] "v"(vv[G].z), [v3] "v"(vv[G].w),                       \
+      [v4] "v"(vv[G + 1].x), [v5] "v"(vv[G + 1].y), [v6] "v"(vv[G + 1].z), [v7] "v"(vv[G + 1].w),       \
+      [v8] "v"(vv[G + 2].x), [v9] "v"(vv[G + 2].y), [v10] "v"(vv[G + 2].z), [v11] "v"(vv[G + 2].w),     \
+      [v12] "v"(vv[G + 3].x), [v13] "v"(vv[G + 3].y), [v14] "v"(vv[G + 3].z), [v15] "v"(vv[G + 3].w)    \
+    : "vcc"
+    if (DIAG) {
+        asm volatile(ALIGNER_HALO16_DIAG_0 ALIGNER_HALO_OPERANDS(0));
+        asm volatile(ALIGNER_HALO16_DIAG_16 ALIGNER_HALO_OPERANDS(4));
+    } else {
+        asm volatile(ALIGNER_HALO16_0 ALIGNER_HALO_OPERANDS(0));
+        asm volatile(ALIGNER_HALO16_16 ALIGNER_HALO_OPERANDS(4));
+    }
+#undef ALIGNER_HALO_OPERANDS
+}
+
+template <bool VEC, int MASKMODE>
+__global__ __launch_bounds__(1024) void maxpath_halo_kernel(MaxpathParams p, int nw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthreads = blockDim.x;
+    const int b = blockIdx.x;
+    int tx, ty;
+    const int mode = classify_lengths(p, b, tx, ty);
+    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    ALIGNER_STAMP(0);
+    ALIGNER_STAMP(6);
+
+    const HaloLds L = halo_lds_layout(nw, p.NT, p.ROWS);
+    float *tiles = reinterpret_cast<float *>(smem + L.tiles);        // [nw][HSLOTS][32][TILE_LD]
+    float *qsave = reinterpret_cast<float *>(smem + L.qsave);        // [nw][HSLOTS][64]
+    float *zrow  = reinterpret_cast<float *>(smem + L.zero);         // 36 zeros (+ wave 0's frame-0 stream)
+    int   *flagp = reinterpret_cast<int *>(smem + L.flag);
+    unsigned *bitsL = reinterpret_cast<unsigned *>(smem + L.bits);   // [NT][ROWS+1]
+    unsigned char *tbl = smem + L.tbl;                               // [NT][ROWS]
+    const int RPB = p.ROWS + 1;
+    const int ntb = (ty + TC - 1) / TC;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int nw_act = (tx + HB - 1) / HB;
+
+    // zrow[0..35] = 0; zrow[36..39]: {max_neg_val, 0, 0, 0} = the first piece of "row -1" in tile 0
+    for (int i = tid; i < TILE_LD + 4; i += nthreads) zrow[i] = (i == TILE_LD) ? p.neg : 0.0f;
+    if (tid == 0) flagp[0] = 0;
+    __syncthreads();
+
+    if (!p.force_exact) {
+        const int w = (wave < nw) ? wave : wave - nw;
+        const bool active = w < nw_act;
+        const int t_lo = active ? w : 0;                             // rows 32w.. start at frame 32w
+        int t_hi = active ? (ty - tx + HB * w + HB - 1) / TC : -1;
+        if (t_hi > ntb - 1) t_hi = ntb - 1;
+        const int ntiles = t_hi - t_lo + 1;
+        if (wave < nw) {
+            // ------------------------------ compute wave ------------------------------
+            const bool real = lane >= HB;
+            const int row = HB * w + lane - HB;                      // halo lanes: rows of the wave above
+            float q = p.neg;
+            float m = (w == 0) ? p.neg : 0.0f;                       // lane 0 is never written by the DPP ops
+            const float *band_lo = tiles + (w > 0 ? w - 1 : 0) * HSLOTS * HB * TILE_LD;   // halo rows' scores
+            const float *band_hi = tiles + w * HSLOTS * HB * TILE_LD;
+            const float *qs_in = qsave + (w > 0 ? w - 1 : 0) * HSLOTS * 64;
+            float *qs_out = qsave + w * HSLOTS * 64;
+
+            for (int i = 0; i < t_lo + w + 1; ++i) __syncthreads();
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const int slot = t % HSLOTS;
+                // ---- resynchronise the halo lanes from the upper wave's registers after tile t-1 ----
+                if (w == 0) {
+                    if (!real) q = (t == 0 && lane == HB - 1) ? 0.0f : p.neg;      // Q[-1,-1] = 0 (core.pyx:24-27)
+                } else {
+                    const float hq = qs_in[((t + HSLOTS - 1) % HSLOTS) * 64 + (real ? lane : lane + HB)];
+                    q = real ? q : hq;
+                }
+                // ---- scores: one ds_read_b128 per 4 frames (halo lanes read the band above) ----
+                const float *base;
+                if (real) base = band_hi + (slot * HB + (lane - HB)) * TILE_LD;
+                else if (w > 0) base = band_lo + (slot * HB + lane) * TILE_LD;
+                else base = zrow;
+                const lds_f32x4 *src = (const lds_f32x4 *)base;
+                float4 vv[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 r = src[g];
+                    vv[g] = make_float4(r.x, r.y, r.z, r.w);
+                }
+                if (w == 0 && t == 0 && lane == HB - 1) vv[0].x = p.neg;           // Q[-1,0] = max_neg_val
+                const int y0 = t * TC;
+                unsigned nbits = 0u;
+                int B = lane;
+                if (t == w) sweep_tile_halo<true>(q, m, nbits, B, vv, row - y0, p.neg);   // the diagonal's tile
+                else        sweep_tile_halo<false>(q, m, nbits, B, vv, row - y0, p.neg);
+                qs_out[slot * 64 + lane] = q;                                      // for the wave below
+                if (real) {
+                    bitsL[t * RPB + row] = ~nbits;                                 // frame 32t+c <-> bit 31-c
+                    tbl[t * p.ROWS + row] = (unsigned char)(lane - B);             // rows climbed inside tile t
+                }
+                __syncthreads();
+            }
+            for (int i = 0; i < ntb + nw - w - t_hi - 2; ++i) __syncthreads();
+        } else {
+            // ------------------------------ loader wave -------------------------------
+            if (active) {
+                const int rr = lane >> 3, cg = lane & 7;
+                float *mytiles = tiles + w * HSLOTS * HB * TILE_LD + rr * TILE_LD + 4 * cg;
+                const float *ub = p.value + ubase;
+                const float *mb = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + ubase : nullptr;
+                unsigned rowoff[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int r = HB * w + 8 * k + rr;
+                    r = r > tx - 1 ? tx - 1 : r;                    // padding rows: replay the last real row
+                    rowoff[k] = (unsigned)r * (unsigned)p.Ty;
+                }
+                unsigned nf = 0u;
+                constexpr int DEPTH = 4;
+                float4 buf[DEPTH][4];
+                auto issue = [&](float4 (&dst)[4], int t) {
+                    const int tc = t < t_hi ? t : t_hi;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        dst[k] = load_tile_piece<VEC, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
+                };
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
+                for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) {
+                        const int t = t_lo + i0 + d;
+                        if (t <= t_hi) {
+                            float *dst = mytiles + (t % HSLOTS) * HB * TILE_LD;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float4 v = buf[d][k];
+                                if (t == ntb - 1) {
+                                    const int c0 = TC * t + 4 * cg;
+                                    v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
+                                    v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
+                                }
+                                *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                const unsigned a = absbits(v.x), bb = absbits(v.y), c = absbits(v.z), dd = absbits(v.w);
+                                const unsigned ab = a > bb ? a : bb, cd = c > dd ? c : dd;
+                                const unsigned mx = ab > cd ? ab : cd;
+                                nf = nf > mx ? nf : mx;
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(buf[d], t + DEPTH);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (t <= t_hi) __syncthreads();
+                    }
+                }
+                if (nf >= 0x7F800000u) flagp[0] = 1;
+                for (int i = 0; i < ntb + nw - w - t_hi - 1; ++i) __syncthreads();
+            } else {
+                for (int i = 0; i < ntb + nw; ++i) __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+    const bool exact = p.force_exact || flagp[0] != 0;
+    if (exact) exact_fallback_sweep<MASKMODE>(p, b, tx, ty, smem, bitsL, RPB);
+    ALIGNER_STAMP(1);
+    __syncthreads();
+
+    // ------------------------------ backtrack ------------------------------
+    int *startsL = reinterpret_cast<int *>(smem);                    // overlays the (dead) score tiles
+    int *Rrow = startsL + ((p.Tx + 1 + 63) / 64) * 64 + 64;          // [NT] path row at each tile's last frame
+    if (exact) {
+        // no transition tables on this path: the generic row walk
+        MaxpathParams pe = p;
+        pe.bits_in_lds = 1;
+        pe.lds_bits_off = L.bits;
+        backtrack_and_store(pe, b, tx, ty, smem);
+        return;
+    }
+    if (wave == 0) {
+        // (1) serial walk through the last tile: rows that start at or after frame 32*(ntb-1)
+        int x = __builtin_amdgcn_readfirstlane(tx - 1);
+        int e = __builtin_amdgcn_readfirstlane(ty - 1);
+        const int tl = ntb - 1;
+        while (x >= 1) {
+            const unsigned word = bitsL[tl * RPB + x];                // uniform address: broadcast read
+            const unsigned mw = __builtin_amdgcn_readfirstlane(word & (0xFFFFFFFFu << ((~e) & (TC - 1))));
+            if (mw == 0u) break;                                     // row x started in an earlier tile
+            const int s = (e | (TC - 1)) - __builtin_ctz(mw);
+            if (lane == 0) startsL[x] = s;
+            e = s - 1;
+            x -= 1;
+            if (e < tl * TC) break;
+        }
+        // (2) the path's row at the last frame of every earlier tile: NT-2 dependent look-ups
+        int r = x;
+        if (lane == 0 && tl >= 1) Rrow[tl - 1] = r;
+        for (int t = tl - 1; t >= 1; --t) {
+            const int mv = tbl[t * p.ROWS + r];
+            r = __builtin_amdgcn_readfirstlane(r - mv);
+            r = r < 0 ? 0 : r;
+            if (lane == 0) Rrow[t - 1] = r;
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < ntb - 1) {
+        // (3) lane = tile: rows (R[t-1], R[t]] start inside tile t; highest set bit at or below `lim`
+        const int t = lane;
+        int xr = Rrow[t];
+        const int xstop = (t >= 1) ? Rrow[t - 1] : 0;
+        int lim = TC - 1;
+        while (xr > xstop) {
+            const unsigned wd = bitsL[t * RPB + xr] & (0xFFFFFFFFu << (TC - 1 - lim));
+            if (wd == 0u) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }   // cannot happen
+            const int c = (TC - 1) - __builtin_ctz(wd);
+            startsL[xr] = t * TC + c;
+            lim = c - 1;
+            xr -= 1;
+            if (lim < 0 && xr > xstop) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
+        }
+    }
+    if (tid == 0) startsL[0] = 0;                                    // row 0 starts at frame 0
+    __syncthreads();
+    for (int r2 = tx + tid; r2 <= p.Tx; r2 += nthreads) startsL[r2] = ty;
+    __syncthreads();
+    ALIGNER_STAMP(3);
+    store_outputs(p, b, tx, ty, startsL);
+    ALIGNER_STAMP(5);
+    ALIGNER_STAMP(7);
+}
+
+// --------------------------------------------------------------------------
 // starts -> dense 0/1 path in the caller's dtype (the reference's return value,
 // __init__.py:21).  Pure streaming store: path[b,x,y] = starts[x] <= y < starts[x+1].
 // --------------------------------------------------------------------------
@@ -861,6 +1136,35 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     const size_t lds_max = (size_t)lds_limit();
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
                      (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
+
+    // halo-lane kernel (opt-in: measured on par with the 63-rows-per-wave kernel at [64,200,1000] --
+    // 5 instead of 6 issues per frame and a 3x faster table-driven backtrack, but 7 instead of 4
+    // compute waves share the CU's SIMDs and LDS)
+    if ((flags & ALIGNER_F_FORCE_HALO) && !(flags & ALIGNER_F_FORCE_GENERIC) && Tx <= 8 * HB && L.NT <= 64) {
+        const int nwh = (Tx + HB - 1) / HB;
+        const HaloLds HL = halo_lds_layout(nwh, L.NT, L.ROWS);
+        const size_t fb = (size_t)2 * (2 * nwh * 64 + 1) * 4;            // exact fallback's column buffers
+        if ((size_t)HL.total <= lds_max && starts_bytes(Tx) + (size_t)L.NT * 4 <= (size_t)HL.bits &&
+            fb <= (size_t)HL.bits) {
+            p.WT = L.NT;
+            p.bits_in_lds = 1;
+            p.lds_bits_off = HL.bits;
+            dim3 grid(B), block(2 * nwh * 64);
+            auto launch = [&](auto kern) {
+                if (HL.total > 64 * 1024) {
+                    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HL.total);
+                    if (e_ != hipSuccess) return fail(ALIGNER_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e_));
+                }
+                hipLaunchKernelGGL(kern, grid, block, (size_t)HL.total, s, p, nwh);
+                hipError_t e2 = hipGetLastError();
+                if (e2 != hipSuccess) return fail(ALIGNER_EHIP, "launch failed: %s", hipGetErrorString(e2));
+                return (int)ALIGNER_OK;
+            };
+            if (vec) return maskmode ? launch(maxpath_halo_kernel<true, 1>) : launch(maxpath_halo_kernel<true, 0>);
+            return maskmode ? launch(maxpath_halo_kernel<false, 1>) : launch(maxpath_halo_kernel<false, 0>);
+        }
+    }
 
     const int nw_need = (Tx + RPW - 1) / RPW;
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8) {

@@ -58,6 +58,8 @@ extern "C" {
                                       result (row t_x-1 all ones) instead of
                                       reporting ALIGNER_ST_BAD_LENGTHS         */
 #define ALIGNER_F_FORCE_GENERIC 4  /* use the generic (barrier-per-frame) kernel */
+#define ALIGNER_F_FORCE_HALO    8  /* use the halo-lane kernel (Tx <= 256, Ty <= 2048)
+                                      instead of the 63-rows-per-wave kernel        */
 
 /* bits of the device status word (aligner_maxpath_read_status) */
 #define ALIGNER_ST_BAD_LENGTHS  1  /* some utterance had t_x < 1 or t_x > t_y

@@ -45,11 +45,15 @@ def _check_consistency(path, tok, dur, tx, ty):
             assert np.array_equal(path[b].argmax(0)[:ty[b]], tok[b, :ty[b]])
 
 
-@pytest.mark.parametrize("generic", [False, True])
-def test_kats_bit_exact(kats, dev, generic):
+KERNELS = {"wide": {}, "halo": {"force_halo": True}, "generic": {"force_generic": True}}
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_kats_bit_exact(kats, dev, kernel):
+    """All three forward kernels (63-rows-per-wave pipelined, halo-lane, generic)."""
     import aligner_amd
     for c in kats:
-        p, tok, dur = _hip(c["value"], c["tx"], c["ty"], dev, max_neg_val=c["neg"], force_generic=generic)
+        p, tok, dur = _hip(c["value"], c["tx"], c["ty"], dev, max_neg_val=c["neg"], **KERNELS[kernel])
         assert np.array_equal(p, c["path"].astype(np.int32)), c["tag"]
         _check_consistency(p, tok, dur, c["tx"], c["ty"])
     assert aligner_amd.read_status(dev) == 0
@@ -85,11 +89,13 @@ def test_baseline_configs_match_reference_hashes(appendix_a, dev, tag):
     _check_consistency(p, tok, dur, tx, ty)
 
 
-def test_generic_kernel_agrees_on_c2_varlen(appendix_a, dev):
+@pytest.mark.parametrize("kernel", ["halo", "generic"])
+def test_other_kernels_agree_on_c2(appendix_a, dev, kernel):
     rec, _ = appendix_a
-    v, tx, ty = _config("C2-varlen")
-    p, _, dur = _hip(v, tx, ty, dev, force_generic=True)
-    assert synth.sha256_of(p) == rec["C2-varlen"]["path_sha256"]
+    for tag in ("C2-fixed", "C2-varlen"):
+        v, tx, ty = _config(tag)
+        p, _, dur = _hip(v, tx, ty, dev, **KERNELS[kernel])
+        assert synth.sha256_of(p) == rec[tag]["path_sha256"]
 
 
 def test_random_shapes_vs_oracle(dev):
@@ -114,9 +120,9 @@ def test_random_shapes_vs_oracle(dev):
         ty = rng.integers(1, Ty + 1, B).astype(np.int32)
         tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
         want = _oracle_path(v, tx, ty)
-        for generic in (False, True):
-            p, tok, dur = _hip(v, tx, ty, dev, force_generic=generic)
-            assert np.array_equal(p, want), (it, generic, B, Tx, Ty)
+        for kernel, kw in KERNELS.items():
+            p, tok, dur = _hip(v, tx, ty, dev, **kw)
+            assert np.array_equal(p, want), (it, kernel, B, Tx, Ty)
             _check_consistency(p, tok, dur, tx, ty)
 
 

@@ -40,16 +40,16 @@ def main():
     # --- correctness on golden KATs, both kernels ---
     z = np.load(os.path.join(ROOT, "tests", "golden", "kat_small.npz"))
     n = int(z["n"])
-    for generic in (False, True):
+    for generic in (False, True, "halo"):
         bad = []
         for i in range(n):
             v, tx, ty = z[f"c{i}_value"], z[f"c{i}_tx"], z[f"c{i}_ty"]
             r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
-                                  path_dtype=torch.int32, max_neg_val=float(z[f"c{i}_neg"]), force_generic=generic)
+                                  path_dtype=torch.int32, max_neg_val=float(z[f"c{i}_neg"]), force_generic=(generic is True), force_halo=(generic == "halo"))
             torch.cuda.synchronize()
             if not np.array_equal(r.path.cpu().numpy(), z[f"c{i}_path"].astype(np.int32)):
                 bad.append(str(z["tags"][i]))
-        print("KATs", "generic" if generic else "pipelined", f"{n - len(bad)}/{n} ok", "BAD:", bad[:12], flush=True)
+        print("KATs", {False: "wide", True: "generic", "halo": "halo"}[generic], f"{n - len(bad)}/{n} ok", "BAD:", bad[:12], flush=True)
     print("status", aligner_amd.read_status(dev))
 
     # --- C2 ---

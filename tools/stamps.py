@@ -31,4 +31,7 @@ for k in (1, 2, 3, 5):
     print(f"{names[k]:>11}: wave0 cycles since entry  median {np.median(d):9.0f}  min {d.min():9.0f}  max {d.max():9.0f}   ({np.median(d)/np.median(clk)/1e3:6.2f} us)")
 print("per-wave fwd_done (b=0):", [int(s[0, w, 1] - s[0, 0, 0]) for w in range(nw)])
 start = s[:, 0, 0]
+for w in range(nw):
+    r = s[0, w]
+    if r[8] > 0: print(f"wave {w}: tile10 stamps rel to 8:", [int(r[k] - r[8]) for k in (9, 10, 11, 12)])
 print("block start skew cycles: max-min", int(start.max() - start.min()))
