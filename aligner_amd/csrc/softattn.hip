@@ -129,6 +129,54 @@ __device__ __forceinline__ void stage_text_group(const SoftAttnParams &p, int b,
     }
 }
 
+// Single-row-group path: split the text operand straight from K into LDS (no prep launch).
+// Each workgroup redoes the split for its utterance -- ~100 VALU per thread, cheaper than the
+// extra kernel boundary and the workspace round trip.  `part` collects per-(k-step, half) partial
+// |k|^2 sums so the norm is added in a fixed order.
+template <int KS, int G>
+__device__ __forceinline__ void stage_text_direct(const SoftAttnParams &p, const float *Kb, uint4 *Ahi, uint4 *Alo,
+                                                  float *part) {
+    const int tid = threadIdx.x;
+    constexpr int NIT = (G * KS * 64 + SA_THREADS - 1) / SA_THREADS;
+    // issue every load of this thread first (NIT x 8 strided dwords in flight), convert afterwards
+    float raw[NIT][8];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * SA_THREADS;
+        const int ln = idx & 63;
+        const int s = (idx >> 6) % KS;
+        const int r = (idx >> 6) / KS;
+        const int i = 32 * r + (ln & 31);
+        const int c0 = 16 * s + 8 * (ln >> 5);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+            raw[it][jj] = (idx < G * KS * 64 && i < p.Tx && c0 + jj < p.C) ? Kb[(size_t)(c0 + jj) * p.Tx + i] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * SA_THREADS;
+        if (idx < G * KS * 64) {
+            const int ln = idx & 63;
+            const int s = (idx >> 6) % KS;
+            const int r = (idx >> 6) / KS;
+            bf16x8 h, l;
+            float sq = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float v = raw[it][jj];
+                sq += v * v;
+                __bf16 hh, ll;
+                split_bf16(v, hh, ll);
+                h[jj] = hh;
+                l[jj] = ll;
+            }
+            Ahi[idx] = __builtin_bit_cast(uint4, h);
+            Alo[idx] = __builtin_bit_cast(uint4, l);
+            part[(32 * r + (ln & 31)) * (2 * KS) + 2 * s + (ln >> 5)] = sq;
+        }
+    }
+}
+
 // dot products of one 32-row tile with this wave's 32 frames: 3x bf16 MFMA per k-step
 // (hi*hi + hi*lo + lo*hi).  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 template <int KS>
@@ -214,6 +262,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     uint4 *Ahi = reinterpret_cast<uint4 *>(smem);              // [G][KS][64] bf16x8 fragments
     uint4 *Alo = Ahi + G * KS * 64;                            // [G][KS][64]
     float *kn = reinterpret_cast<float *>(Alo + G * KS * 64);  // [G*32]
+    float *part = kn + G * 32;                                 // [G*32][2*KS] (single-group path only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
@@ -231,16 +280,33 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     const float s2 = scale * LOG2E_F;                  // logits are kept in base 2 (v_exp_f32 is exp2)
 
     SA_STAMP(0);
-    // mel operand: issue the strided loads now, convert after the text operand is staged
+    // mel operand: strided loads, converted after the text operand is staged.  The waves of a
+    // workgroup are split in two groups: the first issues its mel loads before the staging, the
+    // second only after the staging barrier, so that the second group's loads and MFMA/softmax phase
+    // overlap the first group's MFMA/softmax and store phases (all workgroups start together, so
+    // without the stagger the whole GPU alternates between an HBM-read, a compute and an HBM-write phase)
+    const bool early = MULTI || wave < SA_WAVES / 2;
     float qraw[KS][8];
+    if (early) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int c = 16 * s + 8 * half + jj;
-            qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
-        }
-    if (!MULTI) stage_text_group<KS, G>(p, b, 0, Ahi, Alo, kn, tx, l2, s2);
+            for (int jj = 0; jj < 8; ++jj) {
+                const int c = 16 * s + 8 * half + jj;
+                qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+            }
+    }
+    if (!MULTI) stage_text_direct<KS, G>(p, p.keys + (size_t)b * p.C * p.Tx, Ahi, Alo, part);
+    if (!early) {
+        __syncthreads();                      // (the staging barrier, taken early by this group)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int c = 16 * s + 8 * half + jj;
+                qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+            }
+    }
     bf16x8 bhi[KS], blo[KS];
     float qn = 0.f;
 #pragma unroll
@@ -258,6 +324,14 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     SA_STAMP(1);
 
     if (!MULTI) {
+        if (early) __syncthreads();
+        // per-row additive term of the base-2 logit (fixed summation order); -inf masks rows >= t_x
+        for (int il = tid; il < G * 32; il += SA_THREADS) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2 * KS; ++j) acc += part[il * (2 * KS) + j];
+            kn[il] = (il < tx) ? (l2 ? s2 * acc : 0.f) : NEG_INF_F;
+        }
         __syncthreads();
         SA_STAMP(2);
         // lg = logit * log2(e) = acc*dmul + (bias[row] + qterm); bias carries the row mask (-inf)
@@ -522,11 +596,14 @@ static SaLayout sa_layout(int B, int C, int Tx) {
 
 template <int KS, int G, bool MULTI>
 static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaLayout &L, hipStream_t s) {
-    hipLaunchKernelGGL(softattn_prep_kernel<KS>, dim3(L.RT, p.B), dim3(256), 0, s, p.keys,
-                       reinterpret_cast<uint4 *>(ws + L.hi_off), reinterpret_cast<uint4 *>(ws + L.lo_off),
-                       reinterpret_cast<float *>(ws + L.kn_off), p.C, p.Tx, L.RT);
-    ALIGNER_HIP_CHECK(hipGetLastError());
-    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float);
+    if (MULTI) {          // row-group path restages the text operand per group: prepare it once
+        hipLaunchKernelGGL(softattn_prep_kernel<KS>, dim3(L.RT, p.B), dim3(256), 0, s, p.keys,
+                           reinterpret_cast<uint4 *>(ws + L.hi_off), reinterpret_cast<uint4 *>(ws + L.lo_off),
+                           reinterpret_cast<float *>(ws + L.kn_off), p.C, p.Tx, L.RT);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float) +
+                       (MULTI ? 0 : (size_t)G * 32 * 2 * KS * sizeof(float));
     auto kern = softattn_kernel<KS, G, MULTI>;
     if (lds > 64 * 1024)
         ALIGNER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
