@@ -142,7 +142,7 @@ __device__ __forceinline__ bool tile_in_band(int t, int r0, int nrows, int tx, i
 // Token starts -> the caller's outputs.  starts[x] = first frame of token x for
 // x < t_x and t_y for t_x <= x <= Tx, so durations are plain differences and a
 // frame's token is found by bisection.
-__device__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, const int *startsL) {
+__device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, const int *startsL) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
@@ -164,7 +164,7 @@ __device__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, con
 
 // Outputs for the degenerate modes (whole block, uniform): no ones at all, or the
 // reference's t_x > t_y result (row t_x-1 owns every frame).
-__device__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty, int *startsL) {
+__device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty, int *startsL) {
     for (int x = threadIdx.x; x <= p.Tx; x += blockDim.x)
         startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
     __syncthreads();
@@ -194,21 +194,31 @@ __device__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx
 // global memory only) a window of WT tiles x (ROWS+1) words.
 // --------------------------------------------------------------------------
 // One row of the single-window backtrack with everything static: wr[K] holds row (64c+K)'s
-// words (lane = tile).  ~12 scalar/vector issues in the common case, no LDS, no loop.
-template <int K>
+// words (lane = tile).  The common case (the row starts in the word that contains e) is ten
+// scalar/vector issues in one asm statement, no LDS, no loop; `ok == 0` sends the rare long
+// token to the ballot search over the row's earlier words.
+template <int K, bool CHECK>
 __device__ __forceinline__ void walk_row_static(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
                                                 int lane, int *status) {
     const int x = xbase + K;
-    if (x <= xtop && x >= 1) {                                   // uniform
+    if (!CHECK || (x <= xtop && x >= 1)) {                       // uniform
         const unsigned w = wr[K];
-        const int je = e >> 5;
-        const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, je);
-        const unsigned mw = word & (0xFFFFFFFFu << ((~e) & (TC - 1)));
-        int s;
-        if (mw != 0u) {
-            s = (e | (TC - 1)) - __builtin_ctz(mw);
-        } else {
-            const unsigned long long bal = __ballot(lane < je && w != 0u);
+        int s, ok, je, t, word;
+        asm volatile(
+            "s_lshr_b32 %[je], %[e], 5\n\t"                       // tile of frame e
+            "s_not_b32 %[t], %[e]\n\t"                            // low 5 bits: 31 - (e & 31)
+            "s_or_b32 %[s], %[e], 31\n\t"                         // last frame of that tile
+            "v_readlane_b32 %[word], %[w], %[je]\n\t"             // the row's word of that tile
+            "s_lshl_b32 %[t], -1, %[t]\n\t"                       // frames <= e  <->  bits >= 31 - (e & 31)
+            "s_and_b32 %[word], %[word], %[t]\n\t"                // SCC = some decision bit at or before e
+            "s_cselect_b32 %[ok], 1, 0\n\t"
+            "s_ff1_i32_b32 %[t], %[word]\n\t"                     // lowest set bit = latest such frame
+            "s_sub_i32 %[s], %[s], %[t]\n\t"
+            : [je] "=&s"(je), [t] "=&s"(t), [word] "=&s"(word), [s] "=&s"(s), [ok] "=&s"(ok)
+            : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [w] "v"(w)
+            : "scc");
+        if (__builtin_amdgcn_readfirstlane(ok) == 0) {
+            const unsigned long long bal = __ballot(lane < __builtin_amdgcn_readfirstlane(je) && w != 0u);
             if (bal != 0ull) {
                 const int js = 63 - __builtin_clzll(bal);
                 const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w, js);
@@ -224,20 +234,23 @@ __device__ __forceinline__ void walk_row_static(const unsigned (&wr)[64], int xb
     }
 }
 
-template <int K>
+template <int K, int KMIN, bool CHECK>
 struct WalkChunk {
     static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
                                                int lane, int *status) {
-        walk_row_static<K>(wr, xbase, xtop, e, startv, lane, status);
-        WalkChunk<K - 1>::run(wr, xbase, xtop, e, startv, lane, status);
+        walk_row_static<K, CHECK>(wr, xbase, xtop, e, startv, lane, status);
+        WalkChunk<K - 1, KMIN, CHECK>::run(wr, xbase, xtop, e, startv, lane, status);
     }
 };
-template <>
-struct WalkChunk<-1> {
-    static __device__ __forceinline__ void run(const unsigned (&)[64], int, int, int &, int &, int, int *) {}
+template <int KMIN, bool CHECK>
+struct WalkChunk<KMIN, KMIN, CHECK> {
+    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
+                                               int lane, int *status) {
+        walk_row_static<KMIN, CHECK>(wr, xbase, xtop, e, startv, lane, status);
+    }
 };
 
-__device__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem) {
+__device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthreads = blockDim.x;
     const int RP = p.ROWS + 1;
@@ -276,7 +289,10 @@ __device__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int t
                 unsigned wr[64];
 #pragma unroll
                 for (int k = 0; k < 64; ++k) wr[k] = wrow[64 * c + k];      // 64 rows x (lane = tile)
-                WalkChunk<63>::run(wr, 64 * c, x, e, startv, lane, p.status);
+                // the top chunk is ragged (rows above t_x-1 do not exist); chunk 0 stops at row 1
+                if (64 * c + 63 > x)  WalkChunk<63, 0, true>::run(wr, 64 * c, x, e, startv, lane, p.status);
+                else if (c == 0)      WalkChunk<63, 1, false>::run(wr, 0, x, e, startv, lane, p.status);
+                else                  WalkChunk<63, 0, false>::run(wr, 64 * c, x, e, startv, lane, p.status);
                 if (c == 0) startv = (lane == 0) ? 0 : startv;              // row 0 starts at frame 0
                 startsL[64 * c + lane] = startv;
             }
