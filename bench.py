@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per duration all-gather bucket (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
     args = ap.parse_args()
 
