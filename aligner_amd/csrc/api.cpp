@@ -3,6 +3,9 @@
 #include <cstdarg>
 #include <cstdio>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace aligner {
@@ -13,6 +16,18 @@ char *error_buffer() {
 }
 
 unsigned long long *g_debug_stamps = nullptr;
+
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::unordered_map<const void *, size_t> granted;      // per device would be stricter; one GPU per process
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(kernel);
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[kernel] = bytes;
+    return e;
+}
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;

@@ -33,6 +33,10 @@ inline int dtype_size(int dt) {
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call: do it once per kernel and size,
+// not on every launch (returns hipSuccess when nothing had to be done)
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 // development aid shared by the kernel files (aligner_debug_set_stamps)
 extern unsigned long long *g_debug_stamps;
 

@@ -1083,9 +1083,7 @@ static int pick_window(int NT, int ROWS, int Tx, size_t budget) {
 
 template <typename K>
 static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, MaxpathParams p) {
-    if (lds > 64 * 1024)
-        ALIGNER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
@@ -1167,11 +1165,8 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
             p.lds_bits_off = HL.bits;
             dim3 grid(B), block(2 * nwh * 64);
             auto launch = [&](auto kern) {
-                if (HL.total > 64 * 1024) {
-                    hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, HL.total);
-                    if (e_ != hipSuccess) return fail(ALIGNER_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e_));
-                }
+                hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)HL.total);
+                if (e_ != hipSuccess) return fail(ALIGNER_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e_));
                 hipLaunchKernelGGL(kern, grid, block, (size_t)HL.total, s, p, nwh);
                 hipError_t e2 = hipGetLastError();
                 if (e2 != hipSuccess) return fail(ALIGNER_EHIP, "launch failed: %s", hipGetErrorString(e2));

@@ -506,92 +506,117 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
 }
 
 // --------------------------------------------------------------------------
-// 1-D convolution of the text / mel encoders ("same" zero padding, K odd):
-//   y[b,o,t] = act(bias[o] + sum_{i,k} w[o,i,k] x[b,i,t+k-K/2])
-// LDS-tiled fp32: a workgroup computes a 64(out-channels) x 64(frames) tile of
-// one utterance; x rows (with halo) and w slices are staged through LDS in
-// chunks of 16 input channels; each thread owns a 4x4 register tile.
+// 1-D convolution of the text / mel encoders ("same" zero padding, K odd) on the matrix cores:
+// y[b,o,t] = act(bias[o] + sum_{i,k} w[o,i,k] x[b,i,t+k-K/2]) as a GEMM with
+// M = out channels, N = frames, reduction over (in channel, tap).  fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, same 64 FLOP/clk/SIMD as the vector ALU but one
+// VGPR per operand and no VALU issue per FMA).  Workgroup tile 128 x 128 (4 waves, each 2x2 MFMA
+// tiles of 32x32), input channels staged through LDS 16 at a time: x rows with their halo once,
+// w as [ (i,k) ][ o ] so that both fragment reads are one conflict-free ds_read_b32 per lane.
 // --------------------------------------------------------------------------
-constexpr int CV_TO = 64, CV_TT = 64, CV_CI = 16;
+constexpr int CM_CI = 16;
 
-template <int K>
-__global__ __launch_bounds__(256) void conv1d_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                      const float *__restrict__ bias, float *__restrict__ y,
-                                                      int Cin, int Cout, int T, int relu) {
+// WO x WT waves, each AO x AT MFMA tiles of 32x32: workgroup tile (32*WO*AO) out channels x (32*WT*AT) frames.
+// <2,2,2,2> = 128x128 for wide layers; <3,2,1,1> = 96x64 (six waves) for the narrow (<= 96 channel) ones.
+template <int K, int WO, int WT, int AO, int AT>
+__global__ __launch_bounds__(WO * WT * 64) void conv1d_mfma_kernel(const float *__restrict__ x,
+                                                                     const float *__restrict__ w,
+                                                                     const float *__restrict__ bias,
+                                                                     float *__restrict__ y, int Cin, int Cout, int T,
+                                                                     int relu) {
+    constexpr int CM_TO = 32 * WO * AO, CM_TT = 32 * WT * AT, NTHR = WO * WT * 64;
     constexpr int HALO = K / 2;
-    constexpr int XW = CV_TT + 2 * HALO;
-    __shared__ float xs[CV_CI][XW + 1];
-    __shared__ float wsm[CV_CI * K][CV_TO + 1];     // [i*K+k][o]
-    const int tid = threadIdx.x;
+    constexpr int XLD = CM_TT + 2 * HALO + 1;                 // odd-ish row stride
+    constexpr int WLD = CM_TO + 4;                            // [ik][o], padded
+    __shared__ float xs[CM_CI * XLD];
+    __shared__ float wsm[CM_CI * K * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z;
-    const int o0 = blockIdx.y * CV_TO, t0 = blockIdx.x * CV_TT;
-    const int to = (tid >> 4) * 4, tt = (tid & 15) * 4;   // 16x16 threads, 4x4 each
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = 0.f;
+    const int o0 = blockIdx.y * CM_TO, t0 = blockIdx.x * CM_TT;
+    const int wo = (wave / WT) * (32 * AO), wt = (wave % WT) * (32 * AT);   // this wave's corner inside the tile
     const float *xb = x + (size_t)b * Cin * T;
+    f32x16 acc[AO][AT];
+#pragma unroll
+    for (int a = 0; a < AO; ++a)
+#pragma unroll
+        for (int c = 0; c < AT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
-    for (int i0 = 0; i0 < Cin; i0 += CV_CI) {
-        __syncthreads();
-        for (int idx = tid; idx < CV_CI * XW; idx += 256) {
-            const int ii = idx / XW, tl = idx - ii * XW;
+    // register-staged pipeline: the next chunk's global loads are in flight while the MFMA loop
+    // runs on the current LDS image (issue early / write late)
+    constexpr int XN = (CM_CI * (CM_TT + 2 * HALO) + NTHR - 1) / NTHR;
+    constexpr int WN = (CM_CI * K * CM_TO + NTHR - 1) / NTHR;
+    float xr[XN], wr[WN];
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int j = 0; j < XN; ++j) {
+            const int idx = tid + NTHR * j;
+            const int ii = idx / (CM_TT + 2 * HALO), tl = idx - ii * (CM_TT + 2 * HALO);
             const int t = t0 + tl - HALO, i = i0 + ii;
-            xs[ii][tl] = (i < Cin && t >= 0 && t < T) ? xb[(size_t)i * T + t] : 0.f;
+            xr[j] = (idx < CM_CI * (CM_TT + 2 * HALO) && i < Cin && t >= 0 && t < T) ? xb[(size_t)i * T + t] : 0.f;
         }
-        for (int idx = tid; idx < CV_CI * K * CV_TO; idx += 256) {
-            const int ol = idx / (CV_CI * K), ik = idx - ol * (CV_CI * K);   // ik = ii*K + k (contiguous in w)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int idx = tid + NTHR * j;
+            const int ol = idx / (CM_CI * K), ik = idx - ol * (CM_CI * K);      // ik = ii*K + k: contiguous in w
             const int o = o0 + ol, i = i0 + ik / K;
-            wsm[ik][ol] = (o < Cout && i < Cin) ? w[((size_t)o * Cin + i0) * K + ik] : 0.f;
+            wr[j] = (idx < CM_CI * K * CM_TO && o < Cout && i < Cin) ? w[((size_t)o * Cin + i0) * K + ik] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int i0 = 0; i0 < Cin; i0 += CM_CI) {
+        __syncthreads();                                       // previous chunk's fragment reads are done
+#pragma unroll
+        for (int j = 0; j < XN; ++j) {
+            const int idx = tid + NTHR * j;
+            const int ii = idx / (CM_TT + 2 * HALO), tl = idx - ii * (CM_TT + 2 * HALO);
+            if (idx < CM_CI * (CM_TT + 2 * HALO)) xs[ii * XLD + tl] = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int idx = tid + NTHR * j;
+            const int ol = idx / (CM_CI * K), ik = idx - ol * (CM_CI * K);
+            if (idx < CM_CI * K * CM_TO) wsm[ik * WLD + ol] = wr[j];
         }
         __syncthreads();
-#pragma unroll 4
-        for (int ii = 0; ii < CV_CI; ++ii) {
+        if (i0 + CM_CI < Cin) fetch(i0 + CM_CI);
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float wv[4], xv[4];
+        for (int kk = 0; kk < CM_CI * K; kk += 2) {
+            // this lane's reduction index: kk + half  ->  (in channel, tap)
+            const int ik = kk + half;
+            const int ii = ik / K, tap = ik - ii * K;
+            float af[AO], bf[AT];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) wv[a] = wsm[ii * K + k][to + a];
+            for (int a = 0; a < AO; ++a) af[a] = wsm[ik * WLD + wo + 32 * a + l31];         // A[o][ik]
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xv[c] = xs[ii][tt + c + k];
+            for (int c = 0; c < AT; ++c) bf[c] = xs[ii * XLD + wt + 32 * c + l31 + tap];     // B[ik][t]
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+            for (int a = 0; a < AO; ++a)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[a][c] = fmaf(wv[a], xv[c], acc[a][c]);
-            }
+                for (int c = 0; c < AT; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[c], acc[a][c], 0, 0, 0);
         }
     }
+    // C/D layout: col = lane&31 (frame), row = (e&3) + 8*(e>>2) + 4*half (out channel)
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int o = o0 + to + a;
-        if (o >= Cout) continue;
-        const float bv = bias ? bias[o] : 0.f;
+    for (int a = 0; a < AO; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int t = t0 + tt + c;
-            if (t < T) {
-                float v = acc[a][c] + bv;
-                if (relu) v = fmaxf(v, 0.f);
-                y[((size_t)b * Cout + o) * T + t] = v;
+        for (int e = 0; e < 16; ++e) {
+            const int o = o0 + wo + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (o >= Cout) continue;
+            const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+            for (int c = 0; c < AT; ++c) {
+                const int t = t0 + wt + 32 * c + l31;
+                if (t < T) {
+                    float v = acc[a][c][e] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[((size_t)b * Cout + o) * T + t] = v;
+                }
             }
         }
-    }
-}
-
-struct SaLayout { size_t hi_off, lo_off, kn_off, total; int RT, KS; };
-
-static SaLayout sa_layout(int B, int C, int Tx) {
-    SaLayout L;
-    L.RT = (Tx + 31) / 32;
-    const int ks = (C + 15) / 16;
-    L.KS = ks <= 5 ? 5 : ks <= 8 ? 8 : 16;
-    const size_t frag = (size_t)B * L.RT * L.KS * 64 * sizeof(uint4);
-    L.hi_off = 0;
-    L.lo_off = align_up(frag, 256);
-    L.kn_off = L.lo_off + align_up(frag, 256);
-    L.total = L.kn_off + align_up((size_t)B * L.RT * 32 * sizeof(float), 256);
-    return L;
 }
 
 template <int KS, int G, bool MULTI>
@@ -605,9 +630,7 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
     const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float) +
                        (MULTI ? 0 : (size_t)G * 32 * 2 * KS * sizeof(float));
     auto kern = softattn_kernel<KS, G, MULTI>;
-    if (lds > 64 * 1024)
-        ALIGNER_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     dim3 grid((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES), p.B), block(SA_THREADS);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
@@ -656,14 +679,20 @@ int aligner_conv1d_f32(const float *x, const float *w, const float *bias, float 
     if (!x || !w || !y) return fail(ALIGNER_EINVAL, "null pointer");
     if (B < 0 || Cin < 1 || Cout < 1 || T < 1) return fail(ALIGNER_EINVAL, "bad shape");
     if (B == 0) return ALIGNER_OK;
-    if (B > 65535 || (Cout + CV_TO - 1) / CV_TO > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    if (B > 65535) return fail(ALIGNER_EDOM, "grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dim3 grid((T + CV_TT - 1) / CV_TT, (Cout + CV_TO - 1) / CV_TO, B), block(256);
-    switch (K) {
-        case 1: hipLaunchKernelGGL(conv1d_kernel<1>, grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu); break;
-        case 3: hipLaunchKernelGGL(conv1d_kernel<3>, grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu); break;
-        case 5: hipLaunchKernelGGL(conv1d_kernel<5>, grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu); break;
-        default: return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    if (Cout > 96) {
+        dim3 grid((T + 127) / 128, (Cout + 127) / 128, B), block(256);
+        if (grid.y > 65535) return fail(ALIGNER_EDOM, "grid too large");
+        if (K == 1) hipLaunchKernelGGL((conv1d_mfma_kernel<1, 2, 2, 2, 2>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
+        if (K == 3) hipLaunchKernelGGL((conv1d_mfma_kernel<3, 2, 2, 2, 2>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
+        if (K == 5) hipLaunchKernelGGL((conv1d_mfma_kernel<5, 2, 2, 2, 2>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
+    } else {
+        dim3 grid((T + 63) / 64, 1, B), block(384);
+        if (K == 1) hipLaunchKernelGGL((conv1d_mfma_kernel<1, 3, 2, 1, 1>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
+        if (K == 3) hipLaunchKernelGGL((conv1d_mfma_kernel<3, 3, 2, 1, 1>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
+        if (K == 5) hipLaunchKernelGGL((conv1d_mfma_kernel<5, 3, 2, 1, 1>), grid, block, 0, s, x, w, bias, y, Cin, Cout, T, relu);
     }
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;

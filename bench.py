@@ -273,8 +273,16 @@ def main():
         }
         dom = max(kernels, key=lambda k: kernels[k]["us"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
+        # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes of this
+        # same command, gfx950 correction applied; see the note in the file) -- not measured by this run
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel_us": round(kernels[dom]["us"], 2), "algorithmic_bytes": kernels[dom]["bytes"],
                     "all_kernels": {k: {"us": round(v["us"], 2),
                                         "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)}

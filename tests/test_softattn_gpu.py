@@ -107,3 +107,29 @@ def test_pipeline_similarity_then_dp(dev):
     want = np.zeros(v.shape, np.int32)
     O.maximum_path_c(want, v, t_x.numpy().copy(), t_y.numpy().copy())
     assert np.array_equal(res.path.cpu().numpy(), want)
+
+
+def test_c3_shape_full_pipeline(dev):
+    """BASELINE config C3: conv text/mel encoders -> log-probs -> DP on an LJSpeech-shaped batch
+    (80-dim mel, ~900 frames, 512-dim text embeddings); reduced batch so the CPU oracle stays fast."""
+    import aligner_amd
+    from oracle import maxpath_oracle as O
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(33)
+    B, Ct, Cm, Tx, Ty = 6, 512, 80, 180, 900
+    params = aligner_amd.AlignmentEncoderParams.random(Ct, Cm, 80, dev, seed=3)
+    text = torch.randn(B, Ct, Tx, generator=g)
+    mel = torch.randn(B, Cm, Ty, generator=g)
+    t_x = torch.tensor([180, 150, 121, 90, 64, 33], dtype=torch.int32)
+    t_y = torch.tensor([900, 811, 700, 512, 333, 170], dtype=torch.int32)
+    logp, _ = aligner_amd.alignment_encoder(text.to(dev), mel.to(dev), params, t_x=t_x.to(dev))
+    res = aligner_amd.align(logp, t_x.to(dev), t_y.to(dev), path_dtype=torch.int32)
+    torch.cuda.synchronize()
+    cpu = lambda st: [(w.cpu(), b.cpu()) for w, b in st]  # noqa: E731
+    want_lp, _ = S.alignment_encoder(text, mel, cpu(params.key_proj), cpu(params.query_proj), t_x=t_x)
+    assert _cmp(logp, want_lp) < TOL
+    v = logp.cpu().numpy().copy()
+    want = np.zeros(v.shape, np.int32)
+    O.maximum_path_c(want, v, t_x.numpy().copy(), t_y.numpy().copy())
+    assert np.array_equal(res.path.cpu().numpy(), want)          # DP on the HIP log-probs: bit-exact
+    assert int(res.durations.sum()) == int(t_y.sum())
