@@ -619,6 +619,21 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_mfma_kernel(const float *
         }
 }
 
+struct SaLayout { size_t hi_off, lo_off, kn_off, total; int RT, KS; };
+
+static SaLayout sa_layout(int B, int C, int Tx) {
+    SaLayout L;
+    L.RT = (Tx + 31) / 32;
+    const int ks = (C + 15) / 16;
+    L.KS = ks <= 5 ? 5 : ks <= 8 ? 8 : 16;
+    const size_t frag = (size_t)B * L.RT * L.KS * 64 * sizeof(uint4);
+    L.hi_off = 0;
+    L.lo_off = align_up(frag, 256);
+    L.kn_off = L.lo_off + align_up(frag, 256);
+    L.total = L.kn_off + align_up((size_t)B * L.RT * 32 * sizeof(float), 256);
+    return L;
+}
+
 template <int KS, int G, bool MULTI>
 static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaLayout &L, hipStream_t s) {
     if (MULTI) {          // row-group path restages the text operand per group: prepare it once
