@@ -180,8 +180,15 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # rehearsal hook: ALIGNER_BENCH_REHEARSE=1 runs all ranks on GPU 0 over gloo (a 1-GPU box cannot
+        # host an RCCL group with more than one rank); the driver's real runs use RCCL, one GPU per rank
+        if os.environ.get("ALIGNER_BENCH_REHEARSE") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     _lib.require_gpu()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
