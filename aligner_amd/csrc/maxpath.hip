@@ -50,6 +50,7 @@ namespace aligner {
 constexpr int TC       = 32;  // frames per tile == decision bits per word
 constexpr int TILE_LD  = 36;  // dwords per LDS tile row: 32 + 4 pad -> 16B-slot stride 9 (odd)
 constexpr int RING_T   = 4;   // boundary ring depth in tiles
+constexpr int RING_LD  = 64;  // floats per ring slot: 32 used, padded so that all 64 lanes can store unmasked
 constexpr int RPW      = 63;  // text rows per compute wave (lane 0 is the ghost lane)
 constexpr int WS_HDR_BYTES = 256;
 
@@ -554,8 +555,8 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
     ALIGNER_STAMP(6);
 
     float *tiles = reinterpret_cast<float *>(smem);              // [NW][2][64][TILE_LD]
-    float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][TC]: row 63w-1 for wave w
-    int   *flagp = reinterpret_cast<int *>(ring + NW * RING_T * TC);   // [4] non-finite score seen
+    float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][RING_LD]: row 63w-1 for wave w
+    int   *flagp = reinterpret_cast<int *>(ring + NW * RING_T * RING_LD);   // [4] non-finite score seen
     unsigned *bitsL = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);   // [NT][ROWS+1] when in LDS
     const int RPB = p.ROWS + 1;
     const int ntb = (ty + TC - 1) / TC;
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
     const int nw_act = (tx + RPW - 1) / RPW;                    // waves that own at least one real row
 
     // wave 0's ghost lane replays "row -1": max_neg_val for every frame (core.pyx:27)
-    for (int i = tid; i < RING_T * TC; i += NW * 128) ring[i] = p.neg;
+    for (int i = tid; i < RING_T * RING_LD; i += NW * 128) ring[i] = p.neg;
     if (tid == 0) flagp[0] = 0;
     __syncthreads();
 
@@ -585,15 +586,16 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
             unsigned bits = 0u;
             int coll = 0;
             const float *mytiles = tiles + w * 2 * 64 * TILE_LD + lane * TILE_LD;
-            const float *myring = ring + w * RING_T * TC;
-            float *outring = ring + (publish ? w + 1 : w) * RING_T * TC;
-            unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + (row < 0 ? 0 : row);
+            const float *myring = ring + w * RING_T * RING_LD;
+            float *outring = ring + (publish ? w + 1 : w) * RING_T * RING_LD;
+            const int brow = (lane == 0) ? p.ROWS - 1 : row;            // decision word column (ghost lane: padding)
+            unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + brow;
 
             for (int i = 0; i < t_lo + w + 1; ++i) __syncthreads();
             for (int t = t_lo; t <= t_hi; ++t) {
                 // one ds_read_b128 per 4 frames; the padded row stride (9 x 16 B) makes the 16-lane
                 // groups of a b128 read hit 16 different 16-byte slots: conflict-free
-                const lds_f32x4 *src = (const lds_f32x4 *)((lane == 0) ? (myring + (t & (RING_T - 1)) * TC)
+                const lds_f32x4 *src = (const lds_f32x4 *)((lane == 0) ? (myring + (t & (RING_T - 1)) * RING_LD)
                                                                          : (mytiles + (t & 1) * 64 * TILE_LD));
                 float4 vv[8];
 #pragma unroll
@@ -611,11 +613,10 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
                     if (publish) sweep_tile_fast<true, false>(q, m, bits, coll, vv, rrel, p.neg);
                     else         sweep_tile_fast<false, false>(q, m, bits, coll, vv, rrel, p.neg);
                 }
-                if (publish && lane < TC) outring[(t & (RING_T - 1)) * TC + lane] = __builtin_bit_cast(float, coll);
-                if (lane != 0) {                                              // word of (tile t, text row)
-                    if (p.bits_in_lds) bitsL[t * RPB + row] = bits;           // frame 32t+c <-> bit 31-c
-                    else               gbits[(size_t)t * p.ROWS] = bits;
-                }
+                // unmasked stores: lanes >= 32 hit the slot's padding, the ghost lane a padding column
+                if (publish) outring[(t & (RING_T - 1)) * RING_LD + lane] = __builtin_bit_cast(float, coll);
+                if (p.bits_in_lds) bitsL[t * RPB + brow] = bits;              // frame 32t+c <-> bit 31-c
+                else               gbits[(size_t)t * p.ROWS] = bits;
                 bits = 0u;
                 __syncthreads();
             }
@@ -1180,7 +1181,7 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     const int nw_need = (Tx + RPW - 1) / RPW;
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8) {
         const int NW = nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
-        const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * TC) * 4 + 16, 16);
+        const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * RING_LD) * 4 + 16, 16);
         if (fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = 0;
             const size_t bits_lds = (size_t)L.NT * (L.ROWS + 1) * 4;
