@@ -60,6 +60,31 @@ constexpr int SA_THREADS = SA_WAVES * 64;
 constexpr float NEG_INF_F = -__builtin_huge_valf();
 constexpr float LOG2E_F = 1.4426950408889634f, LN2_F = 0.6931471805599453f;
 
+// v or +0.0 without a select on the loaded value (a select fed by a load is turned back into a
+// branch around the load, which serialises the loads)
+__device__ __forceinline__ float and_mask(float v, unsigned m) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m);
+}
+
+// Hand-issued loads for the two operand fetches: with compiler-issued loads the scheduler wraps every
+// masked load in "load, s_waitcnt vmcnt(0), select" and the 40 loads of a lane run one after the other.
+// The compiler does not see these loads' vmcnt; consumers go through wait_regs8, which carries the
+// data dependence ("+v") behind an explicit s_waitcnt (the compiler's own waits stay conservative:
+// vmcnt retires in order).
+__device__ __forceinline__ void gload_dword(float &dst, const float *sbase, unsigned voff_bytes) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff_bytes), "s"(sbase) : "memory");
+}
+template <int CNT>
+__device__ __forceinline__ void wait_regs8(float (&r)[8]) {       // CNT < 0: dependence only, no wait
+    if (CNT >= 0)
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "n"(CNT < 0 ? 0 : (CNT > 63 ? 63 : CNT)) : "memory");
+    else
+        asm volatile(""
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
+
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
@@ -130,52 +155,73 @@ __device__ __forceinline__ void stage_text_group(const SoftAttnParams &p, int b,
 }
 
 // Single-row-group path: split the text operand straight from K into LDS (no prep launch).
-// Each workgroup redoes the split for its utterance -- ~100 VALU per thread, cheaper than the
-// extra kernel boundary and the workspace round trip.  `part` collects per-(k-step, half) partial
-// |k|^2 sums so the norm is added in a fixed order.
-template <int KS, int G>
-__device__ __forceinline__ void stage_text_direct(const SoftAttnParams &p, const float *Kb, uint4 *Ahi, uint4 *Alo,
-                                                  float *part) {
-    const int tid = threadIdx.x;
-    constexpr int NIT = (G * KS * 64 + SA_THREADS - 1) / SA_THREADS;
-    // issue every load of this thread first (NIT x 8 strided dwords in flight), convert afterwards
-    float raw[NIT][8];
+// Wave r owns row tile r: lane (i = lane&31, hh = lane>>5) converts one half of the channels of text
+// row 32r+i, so every global load instruction reads two 128-byte runs of K[c][.], the norm |k_i|^2 is
+// one shuffle away (fixed summation order) and a single barrier publishes fragments + bias.
+// Loads and conversion are separate calls so that the caller can put its mel loads between them:
+// vmcnt retires in order, so the text data (issued first) is converted while the mel loads fly.
+template <int KS>
+struct TextStage {
+    static constexpr int CHG = KS <= 8 ? KS : 8;          // 8-channel groups per thread and pass
+    static constexpr int NCH = KS / CHG;                   // passes (2 for KS == 16)
+    float raw[CHG][8];
+    float nrm = 0.f;
+
+    __device__ __forceinline__ void load(const SoftAttnParams &p, const float *Kb, int pass, int wave, int lane) {
+        const int i = 32 * wave + (lane & 31), hh = lane >> 5;
+        const int ic = i < p.Tx ? i : p.Tx - 1;            // clamped: every load is unconditional (no exec branches)
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * SA_THREADS;
-        const int ln = idx & 63;
-        const int s = (idx >> 6) % KS;
-        const int r = (idx >> 6) / KS;
-        const int i = 32 * r + (ln & 31);
-        const int c0 = 16 * s + 8 * (ln >> 5);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj)
-            raw[it][jj] = (idx < G * KS * 64 && i < p.Tx && c0 + jj < p.C) ? Kb[(size_t)(c0 + jj) * p.Tx + i] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * SA_THREADS;
-        if (idx < G * KS * 64) {
-            const int ln = idx & 63;
-            const int s = (idx >> 6) % KS;
-            const int r = (idx >> 6) / KS;
-            bf16x8 h, l;
-            float sq = 0.f;
+        for (int gi = 0; gi < CHG; ++gi)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const float v = raw[it][jj];
-                sq += v * v;
-                __bf16 hh, ll;
-                split_bf16(v, hh, ll);
-                h[jj] = hh;
-                l[jj] = ll;
+                const int c = 8 * (hh * KS + pass * CHG + gi) + jj;
+                const float v = Kb[(size_t)(c < p.C ? c : p.C - 1) * p.Tx + ic];
+                raw[gi][jj] = and_mask(v, (i < p.Tx && c < p.C) ? ~0u : 0u);
             }
-            Ahi[idx] = __builtin_bit_cast(uint4, h);
-            Alo[idx] = __builtin_bit_cast(uint4, l);
-            part[(32 * r + (ln & 31)) * (2 * KS) + 2 * s + (ln >> 5)] = sq;
+    }
+    // C == 16*KS (no channel padding), single pass: uniform row base + one lane offset for all loads
+    __device__ __forceinline__ void load_fast(const SoftAttnParams &p, const float *Kb, int wave, int lane) {
+        const int i = 32 * wave + (lane & 31), hh = lane >> 5;
+        const int ic = i < p.Tx ? i : p.Tx - 1;
+        const unsigned voff = 4u * (unsigned)(hh * 8 * KS * p.Tx + ic);
+#pragma unroll
+        for (int gi = 0; gi < CHG; ++gi)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) gload_dword(raw[gi][jj], Kb + (size_t)(8 * gi + jj) * p.Tx, voff);
+    }
+    // wait until at most YOUNGER younger loads are outstanding, then zero the rows >= Tx
+    template <int YOUNGER>
+    __device__ __forceinline__ void settle_fast(const SoftAttnParams &p, int wave, int lane) {
+        const unsigned m = (32 * wave + (lane & 31) < p.Tx) ? ~0u : 0u;
+        wait_regs8<YOUNGER>(raw[0]);
+#pragma unroll
+        for (int gi = 1; gi < CHG; ++gi) wait_regs8<-1>(raw[gi]);
+#pragma unroll
+        for (int gi = 0; gi < CHG; ++gi)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) raw[gi][jj] = and_mask(raw[gi][jj], m);
+    }
+    __device__ __forceinline__ void convert(uint4 *Ahi, uint4 *Alo, int pass, int wave, int lane) {
+        const int hh = lane >> 5;
+#pragma unroll
+        for (int gi = 0; gi < CHG; ++gi) {
+            const int g = hh * KS + pass * CHG + gi;       // 8-channel group of this row: k-step g>>1, half g&1
+            bf16x8 h, l;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const float v = raw[gi][jj];
+                nrm = fmaf(v, v, nrm);
+                __bf16 hv, lv;
+                split_bf16(v, hv, lv);
+                h[jj] = hv;
+                l[jj] = lv;
+            }
+            const int o = (wave * KS + (g >> 1)) * 64 + (lane & 31) + 32 * (g & 1);
+            Ahi[o] = __builtin_bit_cast(uint4, h);
+            Alo[o] = __builtin_bit_cast(uint4, l);
         }
     }
-}
+};
 
 // dot products of one 32-row tile with this wave's 32 frames: 3x bf16 MFMA per k-step
 // (hi*hi + hi*lo + lo*hi).  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
@@ -252,22 +298,34 @@ __device__ __forceinline__ float load_mel_fragments(const SoftAttnParams &p, con
 #define SA_STAMP(k)                                                                                   \
     do {                                                                                              \
         if (p.stamps && (threadIdx.x & 63) == 0)                                                      \
-            p.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * SA_WAVES + (threadIdx.x >> 6)) * 8 + (k)] = \
+            p.stamps[((size_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6)) * 8 + (k)] = \
                 __builtin_amdgcn_s_memtime();                                                         \
     } while (0)
 
 template <int KS, int G, bool MULTI>
 __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softattn_kernel(SoftAttnParams p) {
+    static_assert(G <= SA_WAVES, "one staging wave per row tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4 *Ahi = reinterpret_cast<uint4 *>(smem);              // [G][KS][64] bf16x8 fragments
     uint4 *Alo = Ahi + G * KS * 64;                            // [G][KS][64]
     float *kn = reinterpret_cast<float *>(Alo + G * KS * 64);  // [G*32]
-    float *part = kn + G * 32;                                 // [G*32][2*KS] (single-group path only)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
-    const int b = blockIdx.y;
-    const int col = blockIdx.x * (32 * SA_WAVES) + wave * 32 + (lane & 31);
+    // 1-D grid of NQ frame ranges x B utterances.  Workgroups are dealt round-robin over the 8 XCDs
+    // (observed, speed only): keep the NQ workgroups that re-read one utterance's text operand on the
+    // same XCD so its L2 fetches that operand once instead of once per XCD.
+    const int NQ = (p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES);
+    int b, fq;
+    if ((p.B & 7) == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        fq = slot % NQ;
+        b = (slot / NQ) * 8 + xcd;
+    } else {
+        b = blockIdx.x / NQ;
+        fq = blockIdx.x % NQ;
+    }
+    const int col = fq * (32 * SA_WAVES) + wave * 32 + (lane & 31);
     const bool col_ok = col < p.Ty;
     int tx = p.Tx;
     if (p.t_xs) {
@@ -280,32 +338,94 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     const float s2 = scale * LOG2E_F;                  // logits are kept in base 2 (v_exp_f32 is exp2)
 
     SA_STAMP(0);
-    // mel operand: strided loads, converted after the text operand is staged.  The waves of a
-    // workgroup are split in two groups: the first issues its mel loads before the staging, the
-    // second only after the staging barrier, so that the second group's loads and MFMA/softmax phase
-    // overlap the first group's MFMA/softmax and store phases (all workgroups start together, so
-    // without the stagger the whole GPU alternates between an HBM-read, a compute and an HBM-write phase)
+    if (p.stamps && (threadIdx.x & 63) == 0)          // slot 7: entry on the 100 MHz clock all XCDs share
+        p.stamps[((size_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6)) * 8 + 7] =
+            __builtin_amdgcn_s_memrealtime();
+    // The waves of a workgroup form two groups.  Group A (waves 0..3, one per SIMD) issues its mel
+    // loads right behind its share of the text loads and computes at raised priority; group B issues
+    // its mel loads only after the staging barrier and fills the issue slots A leaves, so that B's
+    // loads and MFMA/softmax phase overlap A's compute and A's store phase (all workgroups start
+    // together: without the stagger the whole GPU alternates between an HBM-read, a compute and an
+    // HBM-write phase).
     const bool early = MULTI || wave < SA_WAVES / 2;
     float qraw[KS][8];
-    if (early) {
+    const int colc = col_ok ? col : p.Ty - 1;              // clamped: unconditional loads, select afterwards
+    auto load_mel = [&]() {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int c = 16 * s + 8 * half + jj;
-                qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+                const float v = Qb[(size_t)(c < p.C ? c : p.C - 1) * p.Ty + colc];
+                qraw[s][jj] = and_mask(v, (c < p.C && col_ok) ? ~0u : 0u);
             }
-    }
-    if (!MULTI) stage_text_direct<KS, G>(p, p.keys + (size_t)b * p.C * p.Tx, Ahi, Alo, part);
-    if (!early) {
-        __syncthreads();                      // (the staging barrier, taken early by this group)
+    };
+    // fast operand fetch: no channel padding and few enough loads for the 6-bit vmcnt
+    const bool fastld = !MULTI && KS <= 8 && p.C == 16 * KS;              // uniform
+    auto load_mel_fast = [&]() {
+        const unsigned voff = 4u * (unsigned)(8 * half * p.Ty + colc);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int c = 16 * s + 8 * half + jj;
-                qraw[s][jj] = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+            for (int jj = 0; jj < 8; ++jj) gload_dword(qraw[s][jj], Qb + (size_t)(16 * s + jj) * p.Ty, voff);
+    };
+    auto settle_mel_fast = [&]() {
+        const unsigned mk = col_ok ? ~0u : 0u;
+        wait_regs8<0>(qraw[0]);
+#pragma unroll
+        for (int s = 1; s < KS; ++s) wait_regs8<-1>(qraw[s]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) qraw[s][jj] = and_mask(qraw[s][jj], mk);
+    };
+    if (MULTI) {
+        load_mel();
+    } else {
+        TextStage<KS> ts;
+        const float *Kb = p.keys + (size_t)b * p.C * p.Tx;
+        if (fastld) {
+            if (KS <= 8) {
+                if (wave < G) ts.load_fast(p, Kb, wave, lane);
+                if (early) {
+                    load_mel_fast();
+                    if (wave < G) ts.template settle_fast<8 * KS>(p, wave, lane);    // text in, mel still in flight
+                } else if (wave < G) {
+                    ts.template settle_fast<0>(p, wave, lane);
+                }
             }
+        } else {
+            if (wave < G) ts.load(p, Kb, 0, wave, lane);
+            if (early) load_mel();
+        }
+        if (wave < G) {
+            ts.convert(Ahi, Alo, 0, wave, lane);
+            if (TextStage<KS>::NCH == 2) {
+                ts.load(p, Kb, 1, wave, lane);
+                ts.convert(Ahi, Alo, 1, wave, lane);
+            }
+            // per-row additive term of the base-2 logit: s2*|k_i|^2 (L2) or 0 (dot); -inf masks rows >= t_x
+            const float nrm = ts.nrm + __shfl_xor(ts.nrm, 32);
+            const int i = 32 * wave + (lane & 31);
+            if (lane < 32) kn[i] = (i < tx) ? (l2 ? s2 * nrm : 0.f) : NEG_INF_F;
+        }
+        __syncthreads();
+        SA_STAMP(1);
+        // group B fetches its mel strip now and parks at a second barrier until group A has finished
+        // its matrix + softmax phase: a SIMD's two waves would otherwise split the matrix pipe and A's
+        // stores -- the first bytes this workgroup can write -- would start twice as late
+        if (fastld) {
+            if (KS <= 8) {
+                if (!early) {
+                    load_mel_fast();
+                    __syncthreads();
+                }
+                settle_mel_fast();
+            }
+        } else if (!early) {
+            load_mel();
+            __syncthreads();
+        }
     }
     bf16x8 bhi[KS], blo[KS];
     float qn = 0.f;
@@ -321,51 +441,91 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             blo[s][jj] = l;
         }
     qn += __shfl_xor(qn, 32);
-    SA_STAMP(1);
 
     if (!MULTI) {
-        if (early) __syncthreads();
-        // per-row additive term of the base-2 logit (fixed summation order); -inf masks rows >= t_x
-        for (int il = tid; il < G * 32; il += SA_THREADS) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2 * KS; ++j) acc += part[il * (2 * KS) + j];
-            kn[il] = (il < tx) ? (l2 ? s2 * acc : 0.f) : NEG_INF_F;
-        }
-        __syncthreads();
         SA_STAMP(2);
-        // lg = logit * log2(e) = acc*dmul + (bias[row] + qterm); bias carries the row mask (-inf)
-        const float qterm = l2 ? s2 * qn : 0.f;
+        // lg = logit * log2(e) up to a per-column constant (s2*|q_j|^2 cancels in the softmax over the
+        // text axis): acc*dmul + bias[row]; bias carries the row mask (-inf)
         const float dmul = l2 ? -2.0f * s2 : s2;
+        (void)qn;
         float lg[G][16];
         float m = NEG_INF_F, l = 0.f;                 // running max / sum of 2^(lg - m) over this lane's rows
-        f32x16 acc = tile_dot<KS>(Ahi, Alo, bhi, blo, lane);
+        // One wave per SIMD has to overlap its own matrix and vector work: left alone the compiler runs
+        // all MFMAs and then all VALU (and sched_group_barrier pipelines came out lumpy), so the issue
+        // order is written out: MFMA k of tile r+1, then slice k of tile r's epilogue, with a scheduling
+        // fence after every slot.  Fragments are fetched one k-step ahead, the bias one tile ahead.
+        auto frag = [&](const uint4 *A, int r, int s) { return __builtin_bit_cast(bf16x8, A[(r * KS + s) * 64 + lane]); };
+        auto bias4 = [&](int r, int gq) { return *reinterpret_cast<const float4 *>(kn + 32 * r + 8 * gq + 4 * half); };
+        constexpr int NS = 3 * KS;                    // MFMA slots per tile
+        // slot 0 is left to the last MFMA of the previous tile (its result is not readable yet), slots
+        // 1..4: fma + max of one accumulator quarter each, slot 5: tile statistics, E0..NS-1: exp2 of the
+        // 16 logits, each sum one slot behind its exp (no back-to-back dependent transcendental)
+        constexpr int F0 = 1, E0 = 6;
+        bf16x8 ah = frag(Ahi, 0, 0), al = frag(Alo, 0, 0), ahn = ah, aln = al;
+        float4 bz[4] = {bias4(0, 0), bias4(0, 1), bias4(0, 2), bias4(0, 3)};
+        f32x16 acc, d;
+        auto mfma_slot = [&](int rn, int k) {         // MFMA k of tile rn into d
+            const int s = k / 3, j = k % 3;
+            if (j == 0) {
+                if (s + 1 < KS) { ahn = frag(Ahi, rn, s + 1); aln = frag(Alo, rn, s + 1); }
+                else if (rn + 1 < G) { ahn = frag(Ahi, rn + 1, 0); aln = frag(Alo, rn + 1, 0); }
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bhi[s], d, 0, 0, 0);
+            } else if (j == 1) {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, blo[s], d, 0, 0, 0);
+            } else {
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bhi[s], d, 0, 0, 0);
+                ah = ahn; al = aln;
+            }
+        };
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) mfma_slot(0, k);              // tile 0: overlaps the mel operand split
+        acc = d;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < G; ++r) {
-            // issue the next tile's MFMAs before this tile's VALU epilogue so the two overlap
-            f32x16 acc_next;
-            if (r + 1 < G) acc_next = tile_dot<KS>(Ahi + (r + 1) * KS * 64, Alo + (r + 1) * KS * 64, bhi, blo, lane);
-            float tmax = NEG_INF_F;
+            const bool nxt = r + 1 < G;
+            float tmax = NEG_INF_F, ms = 0.f, ts = 0.f, tp = 0.f;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                // rows 8*gq + 4*half + (0..3) of the tile: one ds_read_b128 of their bias
-                const float4 bz = *reinterpret_cast<const float4 *>(kn + 32 * r + 8 * gq + 4 * half);
-                lg[r][4 * gq + 0] = fmaf(acc[4 * gq + 0], dmul, bz.x + qterm);
-                lg[r][4 * gq + 1] = fmaf(acc[4 * gq + 1], dmul, bz.y + qterm);
-                lg[r][4 * gq + 2] = fmaf(acc[4 * gq + 2], dmul, bz.z + qterm);
-                lg[r][4 * gq + 3] = fmaf(acc[4 * gq + 3], dmul, bz.w + qterm);
-                tmax = fmaxf(fmaxf(tmax, fmaxf(lg[r][4 * gq + 0], lg[r][4 * gq + 1])),
-                             fmaxf(lg[r][4 * gq + 2], lg[r][4 * gq + 3]));
+            for (int e = 0; e < 16; ++e) d[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (nxt) mfma_slot(r + 1, k);
+                if (k >= F0 && k < F0 + 4) {
+                    const int gq = k - F0;
+                    lg[r][4 * gq + 0] = fmaf(acc[4 * gq + 0], dmul, bz[gq].x);
+                    lg[r][4 * gq + 1] = fmaf(acc[4 * gq + 1], dmul, bz[gq].y);
+                    lg[r][4 * gq + 2] = fmaf(acc[4 * gq + 2], dmul, bz[gq].z);
+                    lg[r][4 * gq + 3] = fmaf(acc[4 * gq + 3], dmul, bz[gq].w);
+                    tmax = fmaxf(fmaxf(tmax, lg[r][4 * gq + 0]), lg[r][4 * gq + 1]);      // v_max3_f32
+                    tmax = fmaxf(fmaxf(tmax, lg[r][4 * gq + 2]), lg[r][4 * gq + 3]);
+                    if (nxt) bz[gq] = bias4(r + 1, gq);
+                } else if (k == F0 + 4) {
+                    const float mn = fmaxf(m, tmax);
+                    ms = (mn == NEG_INF_F) ? 0.f : mn;
+                    l = l * __builtin_amdgcn_exp2f((m == NEG_INF_F ? ms : m) - ms);
+                    m = mn;
+                }
+                if (k >= E0) {
+                    if (k > E0) ts = (k == E0 + 1) ? tp : ts + tp;      // the previous slot's exps
+                    bool first = true;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (E0 + e * (NS - E0) / 16 == k) {
+                            const float x = __builtin_amdgcn_exp2f(lg[r][e] - ms);
+                            tp = first ? x : tp + x;
+                            first = false;
+                        }
+                    if (first) tp = 0.f;               // a slot without a logit (NS - E0 > 16)
+                }
+                if (k == NS - 1) l += ts + tp;
+                asm volatile("" : "+v"(l), "+v"(ts), "+v"(tp), "+v"(tmax));   // keep the slice here (the IR sink pass would move it)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const float mn = fmaxf(m, tmax);
-            const float ms = (mn == NEG_INF_F) ? 0.f : mn;
-            float ts = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ts += __builtin_amdgcn_exp2f(lg[r][e] - ms);
-            l = l * __builtin_amdgcn_exp2f((m == NEG_INF_F ? ms : m) - ms) + ts;
-            m = mn;
-            if (r + 1 < G) acc = acc_next;
+            acc = d;
         }
+        if (early) __syncthreads();                   // releases group B (see above)
         SA_STAMP(3);
         // merge the two half-waves (rows 4*half offset) of each column
         const float m_o = __shfl_xor(m, 32), l_o = __shfl_xor(l, 32);
@@ -382,43 +542,56 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
         const int i_lane = 4 * half;
         const float c0 = -lse2 * LN2_F;
         float m2 = NEG_INF_F;
-        if (col_ok) {
+        const bool plain = !p.prior && !p.soft;                              // uniform
+        if (col_ok && plain) {
+            // the common case, kept free of loop-carried state: a uniform row base (scalar) plus one
+            // 32-bit lane offset per store
+            float *const out_b = p.logp + (size_t)b * p.Tx * p.Ty;
+            const int lane_off32 = 4 * half * p.Ty + col;
 #pragma unroll
             for (int r = 0; r < G; ++r) {
-                if (32 * r >= p.Tx) break;                                   // uniform
-                const bool full = 32 * r + 32 <= p.Tx;                       // uniform
-                if (p.prior) {
+                if (32 * r < p.Tx) {                                         // uniform
+                    if (32 * r + 32 <= p.Tx) {                               // uniform: a full tile
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                        float v = fmaf(lg[r][e], LN2_F, c0);
-                        if (full || i_lane + iu < p.Tx) {
-                            v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
-                            p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                        for (int e = 0; e < 16; ++e) {
+                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                            out_b[(size_t)iu * p.Ty + lane_off32] = fmaf(lg[r][e], LN2_F, c0);
                         }
-                        lg[r][e] = v;
-                        m2 = fmaxf(m2, v);
-                    }
-                } else if (full) {
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                        const float v = fmaf(lg[r][e], LN2_F, c0);
-                        lg[r][e] = v;
-                        p.logp[lane_off + (size_t)iu * p.Ty] = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                        const float v = fmaf(lg[r][e], LN2_F, c0);
-                        lg[r][e] = v;
-                        if (i_lane + iu < p.Tx) p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                        for (int e = 0; e < 16; ++e) {
+                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                            if (i_lane + iu < p.Tx) out_b[(size_t)iu * p.Ty + lane_off32] = fmaf(lg[r][e], LN2_F, c0);
+                        }
                     }
                 }
             }
         }
+        if (col_ok && !plain) {
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                const bool full = 32 * r + 32 <= p.Tx;                       // uniform
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                    float v = fmaf(lg[r][e], LN2_F, c0);
+                    if (full || i_lane + iu < p.Tx) {
+                        if (p.prior) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
+                        p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                    }
+                    lg[r][e] = v;
+                    m2 = fmaxf(m2, v);
+                }
+            }
+        }
         SA_STAMP(5);
+        if (p.stamps) {                       // debug only: when have this wave's stores left the CU?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SA_STAMP(6);
+            if ((threadIdx.x & 63) == 0)              // slot 4 (overwritten): drained, on the 100 MHz clock
+                p.stamps[((size_t)blockIdx.x * SA_WAVES + (threadIdx.x >> 6)) * 8 + 4] =
+                    __builtin_amdgcn_s_memrealtime();
+        }
         if (p.soft) {
             // softmax over text of the final log-probs (== exp(logp) when there is no prior)
             float lse2 = 0.f;
@@ -642,11 +815,10 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
                            reinterpret_cast<float *>(ws + L.kn_off), p.C, p.Tx, L.RT);
         ALIGNER_HIP_CHECK(hipGetLastError());
     }
-    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float) +
-                       (MULTI ? 0 : (size_t)G * 32 * 2 * KS * sizeof(float));
+    const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float);
     auto kern = softattn_kernel<KS, G, MULTI>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
-    dim3 grid((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES), p.B), block(SA_THREADS);
+    dim3 grid((unsigned)((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES)) * (unsigned)p.B), block(SA_THREADS);
     hipLaunchKernelGGL(kern, grid, block, lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
