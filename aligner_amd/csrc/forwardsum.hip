@@ -1,0 +1,280 @@
+// Forward-sum alignment objective on MI355X (gfx950): the log-likelihood of ALL monotonic alignments
+// and its gradient (the OTA objective the reference's README.md:21-25,50 points at --
+// not in the snapshot, so the spec is build-defined: DESIGN.md 8, oracle/forward_sum_oracle.py).
+//
+//   alpha[x,y] = logaddexp(alpha[x,y-1], alpha[x-1,y-1]) + logp[x,y]      alpha[0,0] = logp[0,0]
+//   beta [x,y] = logaddexp(beta[x,y+1] + logp[x,y+1], beta[x+1,y+1] + logp[x+1,y+1])   beta[tx-1,ty-1] = 0
+//   loss       = -alpha[tx-1,ty-1]             d loss / d logp[x,y] = -exp(alpha + beta - log Z)
+//
+// i.e. the column recurrence of maximum_path_each (reference core.pyx:17-30) with log-sum-exp for max.
+// Same shape of computation as the DP: a mel frame only couples to the previous one, text rows are
+// independent within a frame.  One workgroup per utterance, one thread per text row, the previous
+// column double-buffered in LDS (one barrier per frame).  The [Tx,Ty] operands are row-major with the
+// mel axis contiguous, so a row-per-thread frame read would be strided: tiles of TW frames are staged
+// through LDS with coalesced row-segment loads/stores, for the log-probs in, alpha out (forward) and
+// alpha in, gradient out (backward).
+//
+// Numerics: fp32 in log space cannot carry alpha ~ -5000 over 1000 frames and still resolve the
+// posterior (an error of 1e-2 in the exponent is 1 % of the value; rounding at magnitude 50 is 2e-6 per
+// add and 2000 adds walk 1e-4 away).  The running column is therefore kept near 0: every frame a
+// uniform drift estimate is subtracted, every FS_RB frames the column maximum (one workgroup
+// reduction), and both go into a double offset (C forward, one value per frame in the workspace;
+// D backward).  The posterior is exp(alpha_hat[x,y] + beta_hat[x,y] + float(C_y + D_y - log Z)).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "aligner_amd.h"
+#include "common.h"
+
+namespace aligner {
+
+constexpr float FS_NEG_INF = -__builtin_huge_valf();
+constexpr int FS_RB = 8;                          // frames between re-basings (divides every tile width)
+
+struct FwdSumParams {
+    const float *logp;      // [B,Tx,Ty]
+    const int   *t_xs, *t_ys;
+    float  *alpha;          // workspace [B,Tx,Ty]: alpha relative to the tile's offset
+    double *offs;           // workspace [B,NT = Ty]: C_y, the offset the stored alpha of frame y is relative to
+    double *logz;           // workspace [B]
+    float  *loss;           // [B]
+    float  *grad;           // [B,Tx,Ty] (backward only)
+    int B, Tx, Ty, NT;
+};
+
+__device__ __forceinline__ float fs_logaddexp(float a, float b) {
+    const float m = fmaxf(a, b);
+    if (m == FS_NEG_INF) return FS_NEG_INF;                // both -inf: a - b would be NaN
+    // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the term is in (0, ln 2], so its absolute error
+    // is <= 1e-7 -- below the rounding of the sum itself -- at a tenth of the instructions of libm's pair
+    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+}
+
+// max over the workgroup (all threads get it); red: >= 17 floats of LDS
+__device__ __forceinline__ float fs_block_max(float v, float *red, int tid, int nth) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < (nth >> 6); ++w) r = fmaxf(r, red[w]);
+    __syncthreads();
+    return r;
+}
+
+// ---- forward: alpha tiles, per-tile offsets, log Z, loss ----
+template <int TW>
+__global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
+    constexpr int LD = TW + 1;
+    float *tin = fs_smem;                         // [nth][LD]
+    float *tout = tin + nth * LD;                 // [nth][LD]
+    float *col = tout + nth * LD;                 // [2][nth+1], entry x+1 = row x; entry 0 = row -1 = -inf
+    float *red = col + 2 * (nth + 1);             // [17]
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int x = tid;
+    if (!ok) {                                    // no monotonic alignment exists: loss = +inf
+        if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
+        for (int t = tid; t < p.NT; t += nth) p.offs[(size_t)b * p.NT + t] = 0.0;
+        return;
+    }
+    const int ntl = (ty + TW - 1) / TW;
+    if (tid == 0) { col[0] = FS_NEG_INF; col[nth + 1] = FS_NEG_INF; }
+    col[x + 1] = FS_NEG_INF;
+    float prev = FS_NEG_INF, drift = 0.f;
+    double C = 0.0;
+    int cur = 0;
+    __syncthreads();
+    for (int t = 0; t < ntl; ++t) {
+        const int y0 = t * TW;
+        for (int idx = tid; idx < nth * TW; idx += nth) {          // coalesced: TW consecutive threads per row segment
+            const int r = idx / TW, c = idx - r * TW;
+            tin[r * LD + c] = (r < tx && y0 + c < ty) ? p.logp[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
+        }
+        __syncthreads();
+        for (int c = 0; c < TW; ++c) {
+            const int y = y0 + c;
+            if (y >= ty) { tout[x * LD + c] = FS_NEG_INF; continue; }                  // uniform
+            const float lp = tin[x * LD + c];
+            float a;
+            if (y == 0) a = (x == 0) ? lp : FS_NEG_INF;
+            else        a = fs_logaddexp(prev, col[cur * (nth + 1) + x]) + lp;          // row x-1 sits in entry x
+            if (x >= tx) a = FS_NEG_INF;
+            a -= drift;                                                  // uniform; -inf stays -inf
+            C += (double)drift;
+            if (tid == 0) p.offs[(size_t)b * p.NT + y] = C;
+            tout[x * LD + c] = a;
+            col[(cur ^ 1) * (nth + 1) + x + 1] = a;
+            prev = a;
+            if (y == ty - 1 && x == tx - 1) {
+                const double lz = (double)a + C;
+                p.logz[b] = lz;
+                p.loss[b] = (float)(-lz);
+            }
+            cur ^= 1;
+            __syncthreads();
+            if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                // re-base the running column on its maximum and learn the per-frame drift
+                float m = fs_block_max(prev, red, tid, nth);
+                if (m == FS_NEG_INF) m = 0.f;
+                C += (double)m;
+                drift += m * (1.0f / FS_RB);
+                prev -= m;
+                col[cur * (nth + 1) + x + 1] = prev;
+                __syncthreads();
+            }
+        }
+        for (int idx = tid; idx < nth * TW; idx += nth) {
+            const int r = idx / TW, c = idx - r * TW;
+            if (r < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)r * p.Ty + y0 + c] = tout[r * LD + c];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- backward: beta on the fly, gradient = -posterior ----
+template <int TW>
+__global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
+    constexpr int LD = TW + 1;
+    float *tlp = fs_smem;                         // [nth][LD] log-probs
+    float *tal = tlp + nth * LD;                  // [nth][LD] alpha (relative to C_t)
+    float *tgr = tal + nth * LD;                  // [nth][LD] gradient out
+    float *col = tgr + nth * LD;                  // [2][nth+1], entry x = row x; entry nth = row nth = -inf
+    float *red = col + 2 * (nth + 1);
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int x = tid;
+    const int ntl = ok ? (ty + TW - 1) / TW : 0;
+    // tiles past the utterance (and everything when no alignment exists): gradient 0
+    for (int t = ntl; t * TW < p.Ty; ++t)
+        for (int idx = tid; idx < nth * TW; idx += nth) {
+            const int r = idx / TW, c = idx - r * TW;
+            if (r < p.Tx && t * TW + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + t * TW + c] = 0.f;
+        }
+    if (!ok) return;
+    const double logz = p.logz[b];
+    col[x] = FS_NEG_INF; col[nth + 1 + x] = FS_NEG_INF;
+    if (tid == 0) { col[nth] = FS_NEG_INF; col[2 * nth + 1] = FS_NEG_INF; }
+    float g_prev = FS_NEG_INF, drift = 0.f;       // g_prev = beta[x,y+1] + logp[x,y+1], relative to D
+    double D = 0.0;
+    int cur = 0;
+    __syncthreads();
+    for (int t = ntl - 1; t >= 0; --t) {
+        const int y0 = t * TW;
+        for (int idx = tid; idx < nth * TW; idx += nth) {
+            const int r = idx / TW, c = idx - r * TW;
+            const bool in = r < tx && y0 + c < ty;
+            tlp[r * LD + c] = in ? p.logp[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
+            tal[r * LD + c] = in ? p.alpha[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
+        }
+        __syncthreads();
+        for (int c = TW - 1; c >= 0; --c) {
+            const int y = y0 + c;
+            if (y >= ty) { tgr[x * LD + c] = 0.f; continue; }                           // uniform
+            const float st = (float)(p.offs[(size_t)b * p.NT + y] + D - logz);          // uniform
+            float beta;
+            if (y == ty - 1) beta = (x == tx - 1) ? 0.f : FS_NEG_INF;
+            else             beta = fs_logaddexp(g_prev, col[cur * (nth + 1) + x + 1]);  // row x+1
+            if (x >= tx) beta = FS_NEG_INF;
+            const float e = tal[x * LD + c] + beta + st;
+            const float post = (e > -80.f) ? expf(e) : 0.f;           // also false for NaN / -inf
+            tgr[x * LD + c] = -post;
+            const float g = beta + tlp[x * LD + c] - drift;
+            D += (double)drift;
+            col[(cur ^ 1) * (nth + 1) + x] = g;
+            g_prev = g;
+            cur ^= 1;
+            __syncthreads();
+            if ((c & (FS_RB - 1)) == 0) {
+                float m = fs_block_max(g_prev, red, tid, nth);
+                if (m == FS_NEG_INF) m = 0.f;
+                D += (double)m;
+                drift += m * (1.0f / FS_RB);
+                g_prev -= m;
+                col[cur * (nth + 1) + x] = g_prev;
+                __syncthreads();
+            }
+        }
+        for (int idx = tid; idx < nth * TW; idx += nth) {
+            const int r = idx / TW, c = idx - r * TW;
+            if (r < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + y0 + c] = tgr[r * LD + c];
+        }
+        __syncthreads();
+    }
+}
+
+struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, TW, nth; };
+
+static FsLayout fs_layout(int B, int Tx, int Ty) {
+    FsLayout L;
+    L.nth = ((Tx + 63) / 64) * 64;
+    L.TW = L.nth <= 256 ? 32 : (L.nth <= 512 ? 16 : 8);
+    L.NT = Ty;                                    // one offset per frame
+    L.alpha_off = 0;
+    L.offs_off = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
+    L.logz_off = L.offs_off + align_up((size_t)B * L.NT * sizeof(double), 256);
+    L.total = L.logz_off + align_up((size_t)B * sizeof(double), 256);
+    return L;
+}
+
+template <int TW>
+static int fs_launch(const FwdSumParams &p, const FsLayout &L, bool backward, hipStream_t s) {
+    const size_t lds_f = ((size_t)2 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 17) * sizeof(float);
+    const size_t lds_b = ((size_t)3 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 17) * sizeof(float);
+    auto kf = fwdsum_forward_kernel<TW>;
+    auto kb = fwdsum_backward_kernel<TW>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
+    hipLaunchKernelGGL(kf, dim3(p.B), dim3(L.nth), lds_f, s, p);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    if (backward) {
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
+        hipLaunchKernelGGL(kb, dim3(p.B), dim3(L.nth), lds_b, s, p);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    return ALIGNER_OK;
+}
+
+}  // namespace aligner
+
+using namespace aligner;
+
+extern "C" {
+
+size_t aligner_forward_sum_workspace_bytes(int B, int Tx, int Ty) {
+    if (B < 0 || Tx < 1 || Ty < 1 || Tx > 1024) return 0;
+    return fs_layout(B, Tx, Ty).total;
+}
+
+int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_t *t_ys, float *loss_out,
+                            float *grad_out, void *workspace, size_t workspace_bytes, int B, int Tx, int Ty,
+                            void *stream) {
+    if (!logp || !t_xs || !t_ys || !loss_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
+    if (Tx > 1024) return fail(ALIGNER_EDOM, "Tx=%d exceeds 1024 text rows", Tx);
+    if (B == 0) return ALIGNER_OK;
+    const FsLayout L = fs_layout(B, Tx, Ty);
+    if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    FwdSumParams p{logp, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off),
+                   reinterpret_cast<double *>(ws + L.offs_off), reinterpret_cast<double *>(ws + L.logz_off),
+                   loss_out, grad_out, B, Tx, Ty, L.NT};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bwd = grad_out != nullptr;
+    if (L.TW == 32) return fs_launch<32>(p, L, bwd, s);
+    if (L.TW == 16) return fs_launch<16>(p, L, bwd, s);
+    return fs_launch<8>(p, L, bwd, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+"""The steps either side of the alignment path, on the HIP path (build-defined
+specs -- the reference snapshot only links the OTA paper, README.md:21-25,50):
+
+    forward_sum(logp, t_x, t_y)          -log-likelihood of all monotonic alignments (+ gradient)
+    beta_binomial_prior(t_x, t_y, ...)   the alignment prior soft_attention() can add
+    regulate(h, durations, T_mel)        length regulator: expand text encodings to frames
+
+All arithmetic runs in libaligner_amd.so; torch only owns the buffers.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .softattn import _chk, _stream
+
+_fs_workspaces: dict = {}
+
+
+def _fs_workspace(device, nbytes: int) -> torch.Tensor:
+    ws = _fs_workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _fs_workspaces[device] = ws
+    return ws
+
+
+def _lengths(t: torch.Tensor, name: str, B: int, dev) -> torch.Tensor:
+    t = torch.as_tensor(t).detach().to(device=dev, dtype=torch.int32).contiguous()
+    if t.shape != (B,):
+        raise ValueError(f"{name} must have shape [{B}]")
+    return t
+
+
+def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_grad: bool = True
+                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """loss[B] = -log sum over monotonic alignments of prod_y exp(logp[b, x(y), y]) and, if
+    `want_grad`, d loss / d logp [B,T_text,T_mel] (= minus the posterior occupancy of each cell)."""
+    _lib.require_gpu()
+    lp = _chk(logp, "logp")
+    if lp.dim() != 3:
+        raise ValueError("logp must be [B, T_text, T_mel]")
+    B, Tx, Ty = lp.shape
+    dev = lp.device
+    tx = _lengths(t_x, "t_x", B, dev)
+    ty = _lengths(t_y, "t_y", B, dev)
+    lib = _lib.load()
+    nws = lib.aligner_forward_sum_workspace_bytes(B, Tx, Ty)
+    if nws == 0 and B > 0:
+        raise ValueError(f"unsupported shape B={B} T_text={Tx} T_mel={Ty} (T_text <= 1024)")
+    ws = _fs_workspace(dev, nws)
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    grad = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_grad else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.aligner_forward_sum_f32(lp.data_ptr(), tx.data_ptr(), ty.data_ptr(), loss.data_ptr(),
+                                               None if grad is None else grad.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               B, Tx, Ty, _stream(dev)))
+    return loss, grad
+
+
+def beta_binomial_prior(t_x: torch.Tensor, t_y: torch.Tensor, T_text: int, T_mel: int, scaling: float = 1.0
+                        ) -> torch.Tensor:
+    """prior[B,T_text,T_mel]: BetaBinomial(n=t_x, a=s*(y+1), b=s*(t_y-y)).pmf(x); 0 in the padding."""
+    _lib.require_gpu()
+    t_x = torch.as_tensor(t_x)
+    if not t_x.is_cuda:
+        raise ValueError("t_x must be a GPU tensor")
+    dev = t_x.device
+    B = t_x.shape[0]
+    tx = _lengths(t_x, "t_x", B, dev)
+    ty = _lengths(t_y, "t_y", B, dev)
+    out = torch.empty((B, T_text, T_mel), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().aligner_beta_binomial_prior_f32(tx.data_ptr(), ty.data_ptr(), out.data_ptr(), B, T_text,
+                                                               T_mel, float(scaling), _stream(dev)))
+    return out
+
+
+def regulate(h: torch.Tensor, durations: torch.Tensor, T_mel: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(out[B,C,T_mel], tok[B,T_mel]): out[b,:,y] = h[b,:,tok[b,y]]; frames past sum(durations[b]) are 0 / -1."""
+    _lib.require_gpu()
+    hh = _chk(h, "h")
+    B, C, Tx = hh.shape
+    dev = hh.device
+    dur = torch.as_tensor(durations).detach().to(device=dev, dtype=torch.int32).contiguous()
+    if dur.shape != (B, Tx):
+        raise ValueError("durations must be [B, T_text]")
+    out = torch.empty((B, C, T_mel), dtype=torch.float32, device=dev)
+    tok = torch.empty((B, T_mel), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().aligner_regulate_f32(hh.data_ptr(), dur.data_ptr(), out.data_ptr(), tok.data_ptr(),
+                                                    B, C, Tx, T_mel, _stream(dev)))
+    return out, tok

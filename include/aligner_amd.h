@@ -175,6 +175,35 @@ int aligner_conv1d_f32(const float *x_dev, const float *w_dev, const float *bias
                        float *y_dev, int B, int Cin, int Cout, int T, int K,
                        int relu, void *stream);
 
+/* ---- the callers either side of the path (build-defined specs) ---- */
+
+/*
+ * Forward-sum alignment objective: loss[b] = -log of the summed likelihood of ALL monotonic
+ * alignments of logp[b] -- the column recurrence of maximum_path_each (core.pyx:17-30) with
+ * log-sum-exp in place of max -- and, when grad_out_dev is not NULL, its gradient
+ * d loss / d logp = -(posterior occupancy of each cell), 0 outside [0,t_x) x [0,t_y).
+ *   logp_dev [B,Tx,Ty] fp32 (Tx <= 1024), t_xs_dev/t_ys_dev [B] int32, loss_out_dev [B] fp32
+ *   (+inf where t_x < 1 or t_x > t_y), grad_out_dev optional [B,Tx,Ty] fp32,
+ *   workspace_dev aligner_forward_sum_workspace_bytes(B,Tx,Ty) bytes (the alpha tiles).
+ */
+size_t aligner_forward_sum_workspace_bytes(int B, int Tx, int Ty);
+int aligner_forward_sum_f32(const float *logp_dev, const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                            float *loss_out_dev, float *grad_out_dev,
+                            void *workspace_dev, size_t workspace_bytes,
+                            int B, int Tx, int Ty, void *stream);
+
+/* prior[b,x,y] = BetaBinomial(n = t_x, a = scaling*(y+1), b = scaling*(t_y-y)).pmf(x) for x < t_x,
+ * y < t_y, 0 elsewhere; [B,Tx,Ty] fp32, the `prior_dev` operand of aligner_softattn_f32. */
+int aligner_beta_binomial_prior_f32(const int32_t *t_xs_dev, const int32_t *t_ys_dev, float *prior_out_dev,
+                                    int B, int Tx, int Ty, float scaling, void *stream);
+
+/* Length regulator: out[b,c,y] = h[b,c,x(y)] where x(y) is the token whose duration interval holds
+ * frame y (durations as aligner_maxpath_f32 writes them, negative values count as 0); frames past
+ * sum(durations[b]) are 0.  h_dev [B,C,Tx], durations_dev [B,Tx] int32, out_dev optional [B,C,Ty],
+ * tok_out_dev optional [B,Ty] int32 (-1 past the end). */
+int aligner_regulate_f32(const float *h_dev, const int32_t *durations_dev, float *out_dev, int32_t *tok_out_dev,
+                         int B, int C, int Tx, int Ty, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
