@@ -32,6 +32,12 @@ namespace aligner {
 
 constexpr float FS_NEG_INF = -__builtin_huge_valf();
 constexpr int FS_RB = 8;                          // frames between re-basings (divides every tile width)
+// the tile width is chosen from the workgroup size (fs_layout): 32 frames up to 256 threads, 16 up to 512
+#define FS_THREADS(TW) ((TW) == 32 ? 256 : (TW) == 16 ? 512 : 1024)
+
+// workgroup barrier for LDS traffic only: __syncthreads() also waits for the global stores / prefetches
+// in flight (vmcnt(0)), which would put a memory round trip into every frame
+__device__ __forceinline__ void fs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct FwdSumParams {
     const float *logp;      // [B,Tx,Ty]
@@ -57,23 +63,25 @@ __device__ __forceinline__ float fs_block_max(float v, float *red, int tid, int 
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
+    fs_lds_barrier();
     float r = red[0];
     for (int w = 1; w < (nth >> 6); ++w) r = fmaxf(r, red[w]);
-    __syncthreads();
+    fs_lds_barrier();
     return r;
 }
 
 // ---- forward: alpha tiles, per-tile offsets, log Z, loss ----
 template <int TW>
-__global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
+__global__ __launch_bounds__(FS_THREADS(TW)) void fwdsum_forward_kernel(FwdSumParams p) {
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
     constexpr int LD = TW + 1;
     float *tin = fs_smem;                         // [nth][LD]
     float *tout = tin + nth * LD;                 // [nth][LD]
     float *col = tout + nth * LD;                 // [2][nth+1], entry x+1 = row x; entry 0 = row -1 = -inf
-    float *red = col + 2 * (nth + 1);             // [17]
+    float *red = col + 2 * (nth + 1);             // [17 + 1 pad]
+    double *toff = reinterpret_cast<double *>(red + 18);   // [TW] this tile's per-frame offsets (a global store per
+                                                  // frame would put a memory round trip before every barrier)
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
@@ -91,14 +99,32 @@ __global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
     float prev = FS_NEG_INF, drift = 0.f;
     double C = 0.0;
     int cur = 0;
-    __syncthreads();
+    float pre[TW];                                // the next tile, in flight
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < TW; ++it) {
+            const int idx = tid + it * nth;
+            const int r = idx / TW, c = idx - r * TW;
+            const int rc = r < tx ? r : tx - 1, yc = t * TW + c < ty ? t * TW + c : ty - 1;
+            pre[it] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+        }
+    };
+    fs_lds_barrier();
     for (int t = 0; t < ntl; ++t) {
         const int y0 = t * TW;
-        for (int idx = tid; idx < nth * TW; idx += nth) {          // coalesced: TW consecutive threads per row segment
+        // coalesced: TW consecutive threads per row segment.  Every load is unconditional (row and frame
+        // clamped into the utterance: the duplicates land in cells the sweep overrides or skips) -- a load
+        // behind a bounds test is compiled to "load, wait, select" and the tile would arrive one element
+        // at a time -- and tile t+1 is fetched into registers while tile t is swept.
+        if (t == 0) fetch(0);
+#pragma unroll
+        for (int it = 0; it < TW; ++it) {
+            const int idx = tid + it * nth;
             const int r = idx / TW, c = idx - r * TW;
-            tin[r * LD + c] = (r < tx && y0 + c < ty) ? p.logp[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
+            tin[r * LD + c] = pre[it];
         }
-        __syncthreads();
+        fs_lds_barrier();
+        fetch(t + 1 < ntl ? t + 1 : t);
         for (int c = 0; c < TW; ++c) {
             const int y = y0 + c;
             if (y >= ty) { tout[x * LD + c] = FS_NEG_INF; continue; }                  // uniform
@@ -109,7 +135,7 @@ __global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
             if (x >= tx) a = FS_NEG_INF;
             a -= drift;                                                  // uniform; -inf stays -inf
             C += (double)drift;
-            if (tid == 0) p.offs[(size_t)b * p.NT + y] = C;
+            if (tid == 0) toff[c] = C;
             tout[x * LD + c] = a;
             col[(cur ^ 1) * (nth + 1) + x + 1] = a;
             prev = a;
@@ -119,7 +145,7 @@ __global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
                 p.loss[b] = (float)(-lz);
             }
             cur ^= 1;
-            __syncthreads();
+            fs_lds_barrier();
             if ((c & (FS_RB - 1)) == FS_RB - 1) {
                 // re-base the running column on its maximum and learn the per-frame drift
                 float m = fs_block_max(prev, red, tid, nth);
@@ -128,20 +154,21 @@ __global__ __launch_bounds__(1024) void fwdsum_forward_kernel(FwdSumParams p) {
                 drift += m * (1.0f / FS_RB);
                 prev -= m;
                 col[cur * (nth + 1) + x + 1] = prev;
-                __syncthreads();
+                fs_lds_barrier();
             }
         }
         for (int idx = tid; idx < nth * TW; idx += nth) {
             const int r = idx / TW, c = idx - r * TW;
             if (r < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)r * p.Ty + y0 + c] = tout[r * LD + c];
         }
-        __syncthreads();
+        if (tid < TW && y0 + tid < ty) p.offs[(size_t)b * p.NT + y0 + tid] = toff[tid];
+        fs_lds_barrier();
     }
 }
 
 // ---- backward: beta on the fly, gradient = -posterior ----
 template <int TW>
-__global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
+__global__ __launch_bounds__(FS_THREADS(TW)) void fwdsum_backward_kernel(FwdSumParams p) {
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
     constexpr int LD = TW + 1;
@@ -150,6 +177,7 @@ __global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
     float *tgr = tal + nth * LD;                  // [nth][LD] gradient out
     float *col = tgr + nth * LD;                  // [2][nth+1], entry x = row x; entry nth = row nth = -inf
     float *red = col + 2 * (nth + 1);
+    double *toff = reinterpret_cast<double *>(red + 18);   // [TW] this tile's per-frame forward offsets
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
@@ -170,20 +198,35 @@ __global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
     float g_prev = FS_NEG_INF, drift = 0.f;       // g_prev = beta[x,y+1] + logp[x,y+1], relative to D
     double D = 0.0;
     int cur = 0;
-    __syncthreads();
+    float pre[TW], prea[TW];                      // the next tile's log-probs and alpha, in flight
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < TW; ++it) {
+            const int idx = tid + it * nth;
+            const int r = idx / TW, c = idx - r * TW;
+            const int rc = r < tx ? r : tx - 1, yc = t * TW + c < ty ? t * TW + c : ty - 1;
+            pre[it] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+            prea[it] = p.alpha[ubase + (size_t)rc * p.Ty + yc];
+        }
+    };
+    fs_lds_barrier();
     for (int t = ntl - 1; t >= 0; --t) {
         const int y0 = t * TW;
-        for (int idx = tid; idx < nth * TW; idx += nth) {
+        if (t == ntl - 1) fetch(t);                // unconditional, batched, one tile ahead (see the forward kernel)
+#pragma unroll
+        for (int it = 0; it < TW; ++it) {
+            const int idx = tid + it * nth;
             const int r = idx / TW, c = idx - r * TW;
-            const bool in = r < tx && y0 + c < ty;
-            tlp[r * LD + c] = in ? p.logp[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
-            tal[r * LD + c] = in ? p.alpha[ubase + (size_t)r * p.Ty + y0 + c] : FS_NEG_INF;
+            tlp[r * LD + c] = pre[it];
+            tal[r * LD + c] = prea[it];
         }
-        __syncthreads();
+        if (tid < TW) toff[tid] = (y0 + tid < ty) ? p.offs[(size_t)b * p.NT + y0 + tid] : 0.0;
+        fs_lds_barrier();
+        fetch(t > 0 ? t - 1 : 0);
         for (int c = TW - 1; c >= 0; --c) {
             const int y = y0 + c;
             if (y >= ty) { tgr[x * LD + c] = 0.f; continue; }                           // uniform
-            const float st = (float)(p.offs[(size_t)b * p.NT + y] + D - logz);          // uniform
+            const float st = (float)(toff[c] + D - logz);                              // uniform
             float beta;
             if (y == ty - 1) beta = (x == tx - 1) ? 0.f : FS_NEG_INF;
             else             beta = fs_logaddexp(g_prev, col[cur * (nth + 1) + x + 1]);  // row x+1
@@ -196,7 +239,7 @@ __global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
             col[(cur ^ 1) * (nth + 1) + x] = g;
             g_prev = g;
             cur ^= 1;
-            __syncthreads();
+            fs_lds_barrier();
             if ((c & (FS_RB - 1)) == 0) {
                 float m = fs_block_max(g_prev, red, tid, nth);
                 if (m == FS_NEG_INF) m = 0.f;
@@ -204,14 +247,14 @@ __global__ __launch_bounds__(1024) void fwdsum_backward_kernel(FwdSumParams p) {
                 drift += m * (1.0f / FS_RB);
                 g_prev -= m;
                 col[cur * (nth + 1) + x] = g_prev;
-                __syncthreads();
+                fs_lds_barrier();
             }
         }
         for (int idx = tid; idx < nth * TW; idx += nth) {
             const int r = idx / TW, c = idx - r * TW;
             if (r < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + y0 + c] = tgr[r * LD + c];
         }
-        __syncthreads();
+        fs_lds_barrier();
     }
 }
 
@@ -231,8 +274,9 @@ static FsLayout fs_layout(int B, int Tx, int Ty) {
 
 template <int TW>
 static int fs_launch(const FwdSumParams &p, const FsLayout &L, bool backward, hipStream_t s) {
-    const size_t lds_f = ((size_t)2 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 17) * sizeof(float);
-    const size_t lds_b = ((size_t)3 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 17) * sizeof(float);
+    // (the float part is an even number of words, so the double offsets behind it are 8-byte aligned)
+    const size_t lds_f = ((size_t)2 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 18) * sizeof(float) + TW * sizeof(double);
+    const size_t lds_b = ((size_t)3 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 18) * sizeof(float) + TW * sizeof(double);
     auto kf = fwdsum_forward_kernel<TW>;
     auto kb = fwdsum_backward_kernel<TW>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
