@@ -75,8 +75,8 @@ def test_oracle_degenerate_lengths():
 def test_prior_oracle_is_a_distribution_and_follows_the_diagonal():
     pr = FS.beta_binomial_prior(20, 100)
     assert pr.shape == (20, 100)
-    # pmf over x = 0..n; the oracle keeps x < n, so each frame sums to 1 - pmf(n)
-    assert (pr.sum(axis=0) <= 1.0 + 1e-12).all() and (pr.sum(axis=0) > 0.5).all()
+    # pmf over x = 0..n; the prior keeps x < n, so each frame sums to 1 - pmf(n) (most of it early on)
+    assert (pr.sum(axis=0) <= 1.0 + 1e-12).all() and (pr.sum(axis=0)[:50] > 0.9).all()
     centre = (pr * np.arange(20)[:, None]).sum(axis=0) / pr.sum(axis=0)
     assert np.all(np.diff(centre) > 0)                           # the mass moves down the text with time
 
