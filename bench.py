@@ -215,6 +215,8 @@ def main():
         buckets = [torch.empty((args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
         gathered = [torch.empty((world * args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
 
+    copied = [None] * nstreams                 # per stream: its durations were copied out (N>1)
+
     def run(nsteps: int):
         ge = args.gather_every
         main = torch.cuda.current_stream(dev)
@@ -222,6 +224,8 @@ def main():
             strm.wait_stream(main)
         for i in range(nsteps):
             k = i % nstreams
+            if copied[k] is not None:
+                streams[k].wait_event(copied[k])       # the bucket copy still reads this stream's durations
             with torch.cuda.stream(streams[k]):
                 steps[k]()
             if dist is not None:
@@ -231,6 +235,8 @@ def main():
                 if slot == 0 and done[bi] is not None:
                     cur.wait_event(done[bi])               # bucket bi's previous gather has read it
                 buckets[bi][slot].copy_(steps[k].dur, non_blocking=True)
+                copied[k] = torch.cuda.Event()
+                copied[k].record(cur)
                 if slot == ge - 1 or i == nsteps - 1:
                     comm_stream.wait_stream(cur)
                     with torch.cuda.stream(comm_stream):

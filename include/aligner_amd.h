@@ -175,7 +175,7 @@ int aligner_conv1d_f32(const float *x_dev, const float *w_dev, const float *bias
                        float *y_dev, int B, int Cin, int Cout, int T, int K,
                        int relu, void *stream);
 
-/* ---- the callers either side of the path (SURVEY.md 8f; build-defined specs, DESIGN.md 8) ---- */
+/* ---- the callers either side of the path (SURVEY.md 8f; build-defined specs, DESIGN.md 7) ---- */
 
 /*
  * Forward-sum alignment objective: loss[b] = -log of the summed likelihood of ALL monotonic
