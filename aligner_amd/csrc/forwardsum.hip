@@ -8,18 +8,26 @@
 //
 // i.e. the column recurrence of maximum_path_each (reference core.pyx:17-30) with log-sum-exp for max.
 // Same shape of computation as the DP: a mel frame only couples to the previous one, text rows are
-// independent within a frame.  One workgroup per utterance, one thread per text row, the previous
-// column double-buffered in LDS (one barrier per frame).  The [Tx,Ty] operands are row-major with the
-// mel axis contiguous, so a row-per-thread frame read would be strided: tiles of TW frames are staged
-// through LDS with coalesced row-segment loads/stores, for the log-probs in, alpha out (forward) and
-// alpha in, gradient out (backward).
+// independent within a frame -- and the same remedy for the 1000-step dependent chain: no workgroup
+// barrier inside it.  One workgroup per utterance; ONE wave sweeps the frames, each lane owning R
+// consecutive text rows (R = 4, 8, 16 for T_text <= 256, 512, 1024), so the neighbour row is the
+// lane's own register except for one DPP wave shift per frame, and the R independent cells per lane
+// cover each other's transcendental latency.  The other three waves only move data: the [Tx,Ty]
+// operands are row-major with the mel axis contiguous, so tiles of TW frames are staged through LDS
+// (coalesced row segments from/to HBM, frame-major in LDS so that a lane's R rows of one frame are one
+// ds_read_b128 per four rows), double-buffered, one barrier per tile.
+//
+// Everything inside the kernels is in BASE-2 logs (the stagers scale the log-probs by log2 e on their
+// way into LDS): v_exp_f32 / v_log_f32 are exp2 / log2, so logaddexp is sub, exp2, add, log2, add, max --
+// six issues -- and "minus infinity" is the finite FS_NEG, which absorbs every addend (no NaN from
+// inf - inf, no select).
 //
 // Numerics: fp32 in log space cannot carry alpha ~ -5000 over 1000 frames and still resolve the
 // posterior (an error of 1e-2 in the exponent is 1 % of the value; rounding at magnitude 50 is 2e-6 per
 // add and 2000 adds walk 1e-4 away).  The running column is therefore kept near 0: every frame a
-// uniform drift estimate is subtracted, every FS_RB frames the column maximum (one workgroup
-// reduction), and both go into a double offset (C forward, one value per frame in the workspace;
-// D backward).  The posterior is exp(alpha_hat[x,y] + beta_hat[x,y] + float(C_y + D_y - log Z)).
+// uniform drift estimate is subtracted, every FS_RB frames the column maximum (a wave reduction), and
+// both go into a double offset (C forward, one value per frame in the workspace; D backward).  The
+// posterior is exp(alpha_hat[x,y] + beta_hat[x,y] + float(C_y + D_y - log Z)).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -31,239 +39,308 @@
 namespace aligner {
 
 constexpr float FS_NEG_INF = -__builtin_huge_valf();
+constexpr float FS_NEG = -1e30f;                  // "log 0" inside the kernels: absorbs any finite addend
+constexpr float FS_LOG2E = 1.4426950408889634f;
+constexpr double FS_LN2 = 0.6931471805599453;
 constexpr int FS_RB = 8;                          // frames between re-basings (divides every tile width)
-// the tile width is chosen from the workgroup size (fs_layout): 32 frames up to 256 threads, 16 up to 512
-#define FS_THREADS(TW) ((TW) == 32 ? 256 : (TW) == 16 ? 512 : 1024)
-
-// workgroup barrier for LDS traffic only: __syncthreads() also waits for the global stores / prefetches
-// in flight (vmcnt(0)), which would put a memory round trip into every frame
-__device__ __forceinline__ void fs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int FS_THREADS = 256;                   // wave 0 sweeps, waves 1..3 stage tiles
+constexpr int FS_STAGERS = FS_THREADS - 64;
 
 struct FwdSumParams {
     const float *logp;      // [B,Tx,Ty]
     const int   *t_xs, *t_ys;
-    float  *alpha;          // workspace [B,Tx,Ty]: alpha relative to the tile's offset
-    double *offs;           // workspace [B,NT = Ty]: C_y, the offset the stored alpha of frame y is relative to
-    double *logz;           // workspace [B]
+    float  *alpha;          // workspace [B,Tx,Ty]: log2 alpha of frame y relative to offs[y]
+    double *offs;           // workspace [B,NT = Ty]: C_y (base 2)
+    double *logz;           // workspace [B]: log2 Z
     float  *loss;           // [B]
     float  *grad;           // [B,Tx,Ty] (backward only)
     int B, Tx, Ty, NT;
 };
 
-__device__ __forceinline__ float fs_logaddexp(float a, float b) {
-    const float m = fmaxf(a, b);
-    if (m == FS_NEG_INF) return FS_NEG_INF;                // both -inf: a - b would be NaN
-    // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the term is in (0, ln 2], so its absolute error
-    // is <= 1e-7 -- below the rounding of the sum itself -- at a tenth of the instructions of libm's pair
-    return m + __logf(1.0f + __expf(-fabsf(a - b)));
+// log2(2^a + 2^b).  The log term is in (0, 1]: its absolute error (~1 ulp of the hardware log2/exp2)
+// is below the rounding of the sum itself.  FS_NEG operands: a - b = 0 -> m + 1 = FS_NEG (absorbed).
+__device__ __forceinline__ float fs_lae2(float a, float b) {
+    float m;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));      // (fmaxf would first canonicalise both operands)
+    return m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
 }
 
-// max over the workgroup (all threads get it); red: >= 17 floats of LDS
-__device__ __forceinline__ float fs_block_max(float v, float *red, int tid, int nth) {
+// a log-prob on its way into LDS: base 2, and never below FS_NEG (a -inf score would meet FS_NEG as NaN)
+__device__ __forceinline__ float fs_in(float lp) { return fmaxf(lp * FS_LOG2E, FS_NEG); }
+
+// workgroup barrier for LDS traffic only: __syncthreads() would also wait for the stagers' global
+// stores (vmcnt(0)), a memory round trip per tile
+__device__ __forceinline__ void fs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float fs_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    fs_lds_barrier();
-    float r = red[0];
-    for (int w = 1; w < (nth >> 6); ++w) r = fmaxf(r, red[w]);
-    fs_lds_barrier();
-    return r;
+    return v;
 }
 
-// ---- forward: alpha tiles, per-tile offsets, log Z, loss ----
-template <int TW>
-__global__ __launch_bounds__(FS_THREADS(TW)) void fwdsum_forward_kernel(FwdSumParams p) {
+// lane i <- src[lane i-1]; lane 0 gets `edge`          (wave_shr:1, bound_ctrl off keeps `old`)
+__device__ __forceinline__ float fs_from_lane_below(float edge, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, src), 0x138, 0xf, 0xf, false));
+}
+// lane i <- src[lane i+1]; lane 63 gets `edge`         (wave_shl:1)
+__device__ __forceinline__ float fs_from_lane_above(float edge, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
+}
+
+// ---- forward: alpha (frame y relative to C_y), the offsets, log Z, loss ----
+template <int R>
+__global__ __launch_bounds__(FS_THREADS) void fwdsum_forward_kernel(FwdSumParams p) {
+    // tile: TW frames x 64R rows = 32 KB.  Frame-major in LDS with the row stride padded by 4 floats: the
+    // sweeper's 16-byte accesses stay aligned and conflict-free, and the stagers' transposing accesses
+    // (consecutive lanes = consecutive frames) spread over 8 banks instead of hitting one
+    constexpr int TW = 128 / R, ROWS = 64 * R + 4;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
-    constexpr int LD = TW + 1;
-    float *tin = fs_smem;                         // [nth][LD]
-    float *tout = tin + nth * LD;                 // [nth][LD]
-    float *col = tout + nth * LD;                 // [2][nth+1], entry x+1 = row x; entry 0 = row -1 = -inf
-    float *red = col + 2 * (nth + 1);             // [17 + 1 pad]
-    double *toff = reinterpret_cast<double *>(red + 18);   // [TW] this tile's per-frame offsets (a global store per
-                                                  // frame would put a memory round trip before every barrier)
+    float *tin = fs_smem;                         // [2][TW][ROWS] log-probs, frame-major
+    float *tout = tin + 2 * TW * ROWS;            // [2][TW][ROWS] alpha
+    double *toff = reinterpret_cast<double *>(tout + 2 * TW * ROWS);   // [2][TW]
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const bool sweeper = tid < 64;
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
-    const bool ok = tx >= 1 && tx <= ty;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    const int x = tid;
-    if (!ok) {                                    // no monotonic alignment exists: loss = +inf
+    if (!(tx >= 1 && tx <= ty)) {                 // no monotonic alignment exists: loss = +inf
         if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
-        for (int t = tid; t < p.NT; t += nth) p.offs[(size_t)b * p.NT + t] = 0.0;
+        for (int t = tid; t < p.NT; t += FS_THREADS) p.offs[(size_t)b * p.NT + t] = 0.0;
         return;
     }
     const int ntl = (ty + TW - 1) / TW;
-    if (tid == 0) { col[0] = FS_NEG_INF; col[nth + 1] = FS_NEG_INF; }
-    col[x + 1] = FS_NEG_INF;
-    float prev = FS_NEG_INF, drift = 0.f;
+    float prev[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) prev[j] = FS_NEG;
+    float drift = 0.f;
     double C = 0.0;
-    int cur = 0;
-    float pre[TW];                                // the next tile, in flight
-    auto fetch = [&](int t) {
+    // phase ph: stagers load tile ph and store tile ph-2; the sweeper computes tile ph-1
+    for (int ph = 0; ph < ntl + 2; ++ph) {
+        if (!sweeper) {
+            const int s = tid - 64;
+            if (ph < ntl) {
+                // Every load is unconditional (row and frame clamped into the utterance: the duplicates land
+                // in cells the sweep overrides) -- a load behind a bounds test is compiled to "load, wait,
+                // select" and the tile would arrive one element at a time.
+                float *dst = tin + (ph & 1) * TW * ROWS;
+                const int y0 = ph * TW;
+                constexpr int NEL = TW * 64 * R, NIT = (NEL + FS_STAGERS - 1) / FS_STAGERS;
+                constexpr int BATCH = NIT;               // the whole tile in flight: one memory latency per tile
+                for (int i0 = 0; i0 < NIT; i0 += BATCH) {
+                    float v[BATCH];
 #pragma unroll
-        for (int it = 0; it < TW; ++it) {
-            const int idx = tid + it * nth;
-            const int r = idx / TW, c = idx - r * TW;
-            const int rc = r < tx ? r : tx - 1, yc = t * TW + c < ty ? t * TW + c : ty - 1;
-            pre[it] = p.logp[ubase + (size_t)rc * p.Ty + yc];
-        }
-    };
-    fs_lds_barrier();
-    for (int t = 0; t < ntl; ++t) {
-        const int y0 = t * TW;
-        // coalesced: TW consecutive threads per row segment.  Every load is unconditional (row and frame
-        // clamped into the utterance: the duplicates land in cells the sweep overrides or skips) -- a load
-        // behind a bounds test is compiled to "load, wait, select" and the tile would arrive one element
-        // at a time -- and tile t+1 is fetched into registers while tile t is swept.
-        if (t == 0) fetch(0);
+                    for (int i = 0; i < BATCH; ++i) {
+                        int e = s + (i0 + i) * FS_STAGERS;
+                        e = e < NEL ? e : NEL - 1;
+                        const int r = e / TW, c = e - r * TW;
+                        const int rc = r < tx ? r : tx - 1, yc = y0 + c < ty ? y0 + c : ty - 1;
+                        v[i] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+                    }
 #pragma unroll
-        for (int it = 0; it < TW; ++it) {
-            const int idx = tid + it * nth;
-            const int r = idx / TW, c = idx - r * TW;
-            tin[r * LD + c] = pre[it];
-        }
-        fs_lds_barrier();
-        fetch(t + 1 < ntl ? t + 1 : t);
-        for (int c = 0; c < TW; ++c) {
-            const int y = y0 + c;
-            if (y >= ty) { tout[x * LD + c] = FS_NEG_INF; continue; }                  // uniform
-            const float lp = tin[x * LD + c];
-            float a;
-            if (y == 0) a = (x == 0) ? lp : FS_NEG_INF;
-            else        a = fs_logaddexp(prev, col[cur * (nth + 1) + x]) + lp;          // row x-1 sits in entry x
-            if (x >= tx) a = FS_NEG_INF;
-            a -= drift;                                                  // uniform; -inf stays -inf
-            C += (double)drift;
-            if (tid == 0) toff[c] = C;
-            tout[x * LD + c] = a;
-            col[(cur ^ 1) * (nth + 1) + x + 1] = a;
-            prev = a;
-            if (y == ty - 1 && x == tx - 1) {
-                const double lz = (double)a + C;
-                p.logz[b] = lz;
-                p.loss[b] = (float)(-lz);
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int e = s + (i0 + i) * FS_STAGERS;
+                        if (e < NEL) { const int r = e / TW, c = e - r * TW; dst[c * ROWS + r] = fs_in(v[i]); }
+                    }
+                }
             }
-            cur ^= 1;
-            fs_lds_barrier();
-            if ((c & (FS_RB - 1)) == FS_RB - 1) {
-                // re-base the running column on its maximum and learn the per-frame drift
-                float m = fs_block_max(prev, red, tid, nth);
-                if (m == FS_NEG_INF) m = 0.f;
-                C += (double)m;
-                drift += m * (1.0f / FS_RB);
-                prev -= m;
-                col[cur * (nth + 1) + x + 1] = prev;
-                fs_lds_barrier();
+            if (ph >= 2) {
+                const float *src = tout + (ph & 1) * TW * ROWS;
+                const int y0 = (ph - 2) * TW;
+                for (int e = s; e < TW * 64 * R; e += FS_STAGERS) {
+                    const int r = e / TW, c = e - r * TW;
+                    if (r < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)r * p.Ty + y0 + c] = src[c * ROWS + r];
+                }
+                if (s < TW && y0 + s < ty) p.offs[(size_t)b * p.NT + y0 + s] = toff[(ph & 1) * TW + s];
+            }
+        } else if (ph >= 1 && ph <= ntl) {
+            const int t = ph - 1, y0 = t * TW;
+            const float *src = tin + (t & 1) * TW * ROWS + R * lane;
+            float *dst = tout + (t & 1) * TW * ROWS + R * lane;
+            float4 nx[R / 4];                          // the next frame's log-probs: the LDS read of frame c+1
+#pragma unroll                                         // is in flight while frame c is computed
+            for (int j = 0; j < R; j += 4) nx[j / 4] = *reinterpret_cast<const float4 *>(src + j);
+            for (int c = 0; c < TW; ++c) {
+                const int y = y0 + c;
+                float lp[R];
+#pragma unroll
+                for (int j = 0; j < R; j += 4) {
+                    lp[j] = nx[j / 4].x; lp[j + 1] = nx[j / 4].y; lp[j + 2] = nx[j / 4].z; lp[j + 3] = nx[j / 4].w;
+                }
+                const int cn = c + 1 < TW ? c + 1 : c;
+#pragma unroll
+                for (int j = 0; j < R; j += 4) nx[j / 4] = *reinterpret_cast<const float4 *>(src + cn * ROWS + j);
+                // row -1 is log 1 = 0 for the very first frame (alpha[0,0] = logp[0,0]) and "log 0" afterwards
+                const float up0 = fs_from_lane_below(y == 0 ? 0.f : FS_NEG, prev[R - 1]);
+                float a[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const float v = fs_lae2(prev[j], j ? prev[j - 1] : up0) + (lp[j] - drift);
+                    a[j] = (R * lane + j < tx && y < ty) ? v : FS_NEG;
+                }
+                C += (double)drift;
+                if (lane == 0) toff[(t & 1) * TW + c] = C;
+#pragma unroll
+                for (int j = 0; j < R; j += 4)
+                    *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(a[j], a[j + 1], a[j + 2], a[j + 3]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) prev[j] = a[j];
+                if (y == ty - 1) {                                                  // uniform
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+                        if (R * lane + j == tx - 1) {
+                            const double lz = (double)a[j] + C;                     // log2 Z
+                            p.logz[b] = lz;
+                            p.loss[b] = (float)(-lz * FS_LN2);
+                        }
+                }
+                if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                    // re-base the running column on its maximum and learn the per-frame drift
+                    float m = prev[0];
+#pragma unroll
+                    for (int j = 1; j < R; ++j) m = fmaxf(m, prev[j]);
+                    m = fs_wave_max(m);
+                    if (m < 0.5f * FS_NEG) m = 0.f;                                  // an all-"log 0" column
+                    C += (double)m;
+                    drift += m * (1.0f / FS_RB);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) prev[j] = fmaxf(prev[j] - m, FS_NEG);
+                }
             }
         }
-        for (int idx = tid; idx < nth * TW; idx += nth) {
-            const int r = idx / TW, c = idx - r * TW;
-            if (r < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)r * p.Ty + y0 + c] = tout[r * LD + c];
-        }
-        if (tid < TW && y0 + tid < ty) p.offs[(size_t)b * p.NT + y0 + tid] = toff[tid];
         fs_lds_barrier();
     }
 }
 
 // ---- backward: beta on the fly, gradient = -posterior ----
-template <int TW>
-__global__ __launch_bounds__(FS_THREADS(TW)) void fwdsum_backward_kernel(FwdSumParams p) {
+template <int R>
+__global__ __launch_bounds__(FS_THREADS) void fwdsum_backward_kernel(FwdSumParams p) {
+    constexpr int TW = 64 / R, ROWS = 64 * R + 4; // tile: TW frames x 64R rows = 16 KB (three operands, double-buffered)
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    const int tid = threadIdx.x, nth = blockDim.x, b = blockIdx.x;
-    constexpr int LD = TW + 1;
-    float *tlp = fs_smem;                         // [nth][LD] log-probs
-    float *tal = tlp + nth * LD;                  // [nth][LD] alpha (relative to C_t)
-    float *tgr = tal + nth * LD;                  // [nth][LD] gradient out
-    float *col = tgr + nth * LD;                  // [2][nth+1], entry x = row x; entry nth = row nth = -inf
-    float *red = col + 2 * (nth + 1);
-    double *toff = reinterpret_cast<double *>(red + 18);   // [TW] this tile's per-frame forward offsets
+    float *tlp = fs_smem;                         // [2][TW][ROWS] log-probs
+    float *tal = tlp + 2 * TW * ROWS;             // [2][TW][ROWS] alpha (relative to C_y)
+    float *tgr = tal + 2 * TW * ROWS;             // [2][TW][ROWS] gradient out
+    double *toff = reinterpret_cast<double *>(tgr + 2 * TW * ROWS);    // [2][TW] C_y
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const bool sweeper = tid < 64;
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
     const bool ok = tx >= 1 && tx <= ty;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    const int x = tid;
     const int ntl = ok ? (ty + TW - 1) / TW : 0;
-    // tiles past the utterance (and everything when no alignment exists): gradient 0
-    for (int t = ntl; t * TW < p.Ty; ++t)
-        for (int idx = tid; idx < nth * TW; idx += nth) {
-            const int r = idx / TW, c = idx - r * TW;
-            if (r < p.Tx && t * TW + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + t * TW + c] = 0.f;
-        }
+    // frames past the utterance's last tile (everything when no alignment exists): gradient 0
+    for (int r = 0; r < p.Tx; ++r)
+        for (int y = ntl * TW + tid; y < p.Ty; y += FS_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
     if (!ok) return;
     const double logz = p.logz[b];
-    col[x] = FS_NEG_INF; col[nth + 1 + x] = FS_NEG_INF;
-    if (tid == 0) { col[nth] = FS_NEG_INF; col[2 * nth + 1] = FS_NEG_INF; }
-    float g_prev = FS_NEG_INF, drift = 0.f;       // g_prev = beta[x,y+1] + logp[x,y+1], relative to D
+    float g_prev[R];                              // beta[x,y+1] + logp[x,y+1], relative to D
+#pragma unroll
+    for (int j = 0; j < R; ++j) g_prev[j] = FS_NEG;
+    float drift = 0.f;
     double D = 0.0;
-    int cur = 0;
-    float pre[TW], prea[TW];                      // the next tile's log-probs and alpha, in flight
-    auto fetch = [&](int t) {
+    // phase ph: stagers load tile ntl-1-ph and store tile ntl-1-(ph-2); the sweeper computes tile ntl-1-(ph-1)
+    for (int ph = 0; ph < ntl + 2; ++ph) {
+        if (!sweeper) {
+            const int s = tid - 64;
+            if (ph < ntl) {
+                const int t = ntl - 1 - ph, y0 = t * TW;
+                float *dlp = tlp + (ph & 1) * TW * ROWS, *dal = tal + (ph & 1) * TW * ROWS;
+                constexpr int NEL = TW * 64 * R, NIT = (NEL + FS_STAGERS - 1) / FS_STAGERS;
+                constexpr int BATCH = NIT;
+                for (int i0 = 0; i0 < NIT; i0 += BATCH) {
+                    float v[BATCH], w[BATCH];
 #pragma unroll
-        for (int it = 0; it < TW; ++it) {
-            const int idx = tid + it * nth;
-            const int r = idx / TW, c = idx - r * TW;
-            const int rc = r < tx ? r : tx - 1, yc = t * TW + c < ty ? t * TW + c : ty - 1;
-            pre[it] = p.logp[ubase + (size_t)rc * p.Ty + yc];
-            prea[it] = p.alpha[ubase + (size_t)rc * p.Ty + yc];
-        }
-    };
-    fs_lds_barrier();
-    for (int t = ntl - 1; t >= 0; --t) {
-        const int y0 = t * TW;
-        if (t == ntl - 1) fetch(t);                // unconditional, batched, one tile ahead (see the forward kernel)
+                    for (int i = 0; i < BATCH; ++i) {
+                        int e = s + (i0 + i) * FS_STAGERS;
+                        e = e < NEL ? e : NEL - 1;
+                        const int r = e / TW, c = e - r * TW;
+                        const int rc = r < tx ? r : tx - 1, yc = y0 + c < ty ? y0 + c : ty - 1;
+                        v[i] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+                        w[i] = p.alpha[ubase + (size_t)rc * p.Ty + yc];
+                    }
 #pragma unroll
-        for (int it = 0; it < TW; ++it) {
-            const int idx = tid + it * nth;
-            const int r = idx / TW, c = idx - r * TW;
-            tlp[r * LD + c] = pre[it];
-            tal[r * LD + c] = prea[it];
-        }
-        if (tid < TW) toff[tid] = (y0 + tid < ty) ? p.offs[(size_t)b * p.NT + y0 + tid] : 0.0;
-        fs_lds_barrier();
-        fetch(t > 0 ? t - 1 : 0);
-        for (int c = TW - 1; c >= 0; --c) {
-            const int y = y0 + c;
-            if (y >= ty) { tgr[x * LD + c] = 0.f; continue; }                           // uniform
-            const float st = (float)(toff[c] + D - logz);                              // uniform
-            float beta;
-            if (y == ty - 1) beta = (x == tx - 1) ? 0.f : FS_NEG_INF;
-            else             beta = fs_logaddexp(g_prev, col[cur * (nth + 1) + x + 1]);  // row x+1
-            if (x >= tx) beta = FS_NEG_INF;
-            const float e = tal[x * LD + c] + beta + st;
-            const float post = (e > -80.f) ? expf(e) : 0.f;           // also false for NaN / -inf
-            tgr[x * LD + c] = -post;
-            const float g = beta + tlp[x * LD + c] - drift;
-            D += (double)drift;
-            col[(cur ^ 1) * (nth + 1) + x] = g;
-            g_prev = g;
-            cur ^= 1;
-            fs_lds_barrier();
-            if ((c & (FS_RB - 1)) == 0) {
-                float m = fs_block_max(g_prev, red, tid, nth);
-                if (m == FS_NEG_INF) m = 0.f;
-                D += (double)m;
-                drift += m * (1.0f / FS_RB);
-                g_prev -= m;
-                col[cur * (nth + 1) + x] = g_prev;
-                fs_lds_barrier();
+                    for (int i = 0; i < BATCH; ++i) {
+                        const int e = s + (i0 + i) * FS_STAGERS;
+                        if (e < NEL) {
+                            const int r = e / TW, c = e - r * TW;
+                            dlp[c * ROWS + r] = fs_in(v[i]);
+                            dal[c * ROWS + r] = w[i];
+                        }
+                    }
+                }
+                if (s < TW) toff[(ph & 1) * TW + s] = (y0 + s < ty) ? p.offs[(size_t)b * p.NT + y0 + s] : 0.0;
             }
-        }
-        for (int idx = tid; idx < nth * TW; idx += nth) {
-            const int r = idx / TW, c = idx - r * TW;
-            if (r < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + y0 + c] = tgr[r * LD + c];
+            if (ph >= 2) {
+                const float *src = tgr + (ph & 1) * TW * ROWS;
+                const int y0 = (ntl - 1 - (ph - 2)) * TW;
+                for (int e = s; e < TW * 64 * R; e += FS_STAGERS) {
+                    const int r = e / TW, c = e - r * TW;
+                    if (r < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + y0 + c] = src[c * ROWS + r];
+                }
+            }
+        } else if (ph >= 1 && ph <= ntl) {
+            const int buf = (ph - 1) & 1, y0 = (ntl - 1 - (ph - 1)) * TW;
+            const float *slp = tlp + buf * TW * ROWS + R * lane, *sal = tal + buf * TW * ROWS + R * lane;
+            float *dst = tgr + buf * TW * ROWS + R * lane;
+            for (int c = TW - 1; c >= 0; --c) {
+                const int y = y0 + c;
+                if (y >= ty) {                                                       // uniform: padding frames
+#pragma unroll
+                    for (int j = 0; j < R; j += 4) *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
+                float lp[R], al[R];
+#pragma unroll
+                for (int j = 0; j < R; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(slp + c * ROWS + j);
+                    const float4 w = *reinterpret_cast<const float4 *>(sal + c * ROWS + j);
+                    lp[j] = v.x; lp[j + 1] = v.y; lp[j + 2] = v.z; lp[j + 3] = v.w;
+                    al[j] = w.x; al[j + 1] = w.y; al[j + 2] = w.z; al[j + 3] = w.w;
+                }
+                const float st = (float)(toff[buf * TW + c] + D - logz);            // uniform
+                const float dnR = fs_from_lane_above(FS_NEG, g_prev[0]);             // row below this lane's last one
+                float g[R], gr[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int row = R * lane + j;
+                    float beta;
+                    if (y == ty - 1) beta = (row == tx - 1) ? 0.f : FS_NEG;          // uniform branch
+                    else             beta = fs_lae2(g_prev[j], j + 1 < R ? g_prev[j + 1] : dnR);
+                    if (row >= tx) beta = FS_NEG;
+                    gr[j] = -__builtin_amdgcn_exp2f(al[j] + beta + st);              // 2^(-1e30) = 0
+                    g[j] = fmaxf(beta + (lp[j] - drift), FS_NEG);
+                }
+                D += (double)drift;
+#pragma unroll
+                for (int j = 0; j < R; j += 4)
+                    *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(gr[j], gr[j + 1], gr[j + 2], gr[j + 3]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) g_prev[j] = g[j];
+                if ((c & (FS_RB - 1)) == 0) {
+                    float m = g_prev[0];
+#pragma unroll
+                    for (int j = 1; j < R; ++j) m = fmaxf(m, g_prev[j]);
+                    m = fs_wave_max(m);
+                    if (m < 0.5f * FS_NEG) m = 0.f;
+                    D += (double)m;
+                    drift += m * (1.0f / FS_RB);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) g_prev[j] = fmaxf(g_prev[j] - m, FS_NEG);
+                }
+            }
         }
         fs_lds_barrier();
     }
 }
 
-struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, TW, nth; };
+struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, R; };
 
 static FsLayout fs_layout(int B, int Tx, int Ty) {
     FsLayout L;
-    L.nth = ((Tx + 63) / 64) * 64;
-    L.TW = L.nth <= 256 ? 32 : (L.nth <= 512 ? 16 : 8);
+    L.R = Tx <= 256 ? 4 : (Tx <= 512 ? 8 : 16);   // text rows per lane of the sweeping wave
     L.NT = Ty;                                    // one offset per frame
     L.alpha_off = 0;
     L.offs_off = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
@@ -272,19 +349,19 @@ static FsLayout fs_layout(int B, int Tx, int Ty) {
     return L;
 }
 
-template <int TW>
-static int fs_launch(const FwdSumParams &p, const FsLayout &L, bool backward, hipStream_t s) {
-    // (the float part is an even number of words, so the double offsets behind it are 8-byte aligned)
-    const size_t lds_f = ((size_t)2 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 18) * sizeof(float) + TW * sizeof(double);
-    const size_t lds_b = ((size_t)3 * L.nth * (TW + 1) + 2 * (L.nth + 1) + 18) * sizeof(float) + TW * sizeof(double);
-    auto kf = fwdsum_forward_kernel<TW>;
-    auto kb = fwdsum_backward_kernel<TW>;
+template <int R>
+static int fs_launch(const FwdSumParams &p, bool backward, hipStream_t s) {
+    constexpr int ROWS = 64 * R + 4;
+    const size_t lds_f = (size_t)4 * (128 / R) * ROWS * sizeof(float) + 2 * (128 / R) * sizeof(double);
+    const size_t lds_b = (size_t)6 * (64 / R) * ROWS * sizeof(float) + 2 * (64 / R) * sizeof(double);
+    auto kf = fwdsum_forward_kernel<R>;
+    auto kb = fwdsum_backward_kernel<R>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
-    hipLaunchKernelGGL(kf, dim3(p.B), dim3(L.nth), lds_f, s, p);
+    hipLaunchKernelGGL(kf, dim3(p.B), dim3(FS_THREADS), lds_f, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     if (backward) {
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
-        hipLaunchKernelGGL(kb, dim3(p.B), dim3(L.nth), lds_b, s, p);
+        hipLaunchKernelGGL(kb, dim3(p.B), dim3(FS_THREADS), lds_b, s, p);
         ALIGNER_HIP_CHECK(hipGetLastError());
     }
     return ALIGNER_OK;
@@ -316,9 +393,9 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
                    loss_out, grad_out, B, Tx, Ty, L.NT};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
-    if (L.TW == 32) return fs_launch<32>(p, L, bwd, s);
-    if (L.TW == 16) return fs_launch<16>(p, L, bwd, s);
-    return fs_launch<8>(p, L, bwd, s);
+    if (L.R == 4) return fs_launch<4>(p, bwd, s);
+    if (L.R == 8) return fs_launch<8>(p, bwd, s);
+    return fs_launch<16>(p, bwd, s);
 }
 
 }  // extern "C"
