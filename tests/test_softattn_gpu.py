@@ -27,7 +27,10 @@ def _cmp(got, want, tol=TOL):
 
 @pytest.mark.parametrize("B,C,Tx,Ty,sim", [(2, 80, 50, 130, "l2"), (3, 80, 200, 333, "l2"), (2, 16, 7, 40, "l2"),
                                            (2, 80, 224, 129, "dot"), (2, 96, 100, 260, "l2"), (1, 80, 300, 257, "l2"),
-                                           (2, 80, 500, 700, "l2"), (1, 200, 130, 64, "l2")])
+                                           (2, 80, 500, 700, "l2"), (1, 200, 130, 64, "l2"),
+                                           # C == 16*KS for KS = 8 (hand-issued loads), KS = 16 in one row group
+                                           # (two staging passes), B a multiple of 8 (XCD-aware workgroup map)
+                                           (8, 128, 64, 300, "l2"), (1, 256, 100, 96, "dot"), (16, 80, 40, 600, "l2")])
 def test_logp_matches_oracle(dev, B, C, Tx, Ty, sim):
     import aligner_amd
     from oracle import softattn_oracle as S
@@ -45,6 +48,22 @@ def test_logp_matches_oracle(dev, B, C, Tx, Ty, sim):
     assert (soft.cpu() - want_soft).abs().max().item() < TOL
     # columns are normalised over the valid text rows
     assert torch.allclose(soft.sum(1).cpu(), torch.ones(B, Ty), atol=1e-4)
+
+
+@pytest.mark.parametrize("B,C,Tx,Ty", [(8, 80, 200, 1000), (5, 80, 77, 300), (8, 128, 224, 257)])
+def test_logp_only_path(dev, B, C, Tx, Ty):
+    """No soft output, no prior: the store path the benchmark and the DP pipeline use."""
+    import aligner_amd
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(7 * B + Ty)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    t_x[0] = Tx
+    want, _ = S.soft_attention(k, q, t_x=t_x)
+    got, none = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev))
+    torch.cuda.synchronize()
+    assert none is None and _cmp(got, want) < TOL
 
 
 def test_prior_and_sharp_temperature(dev):

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Per-config timings of the hot path on one MI355X (BASELINE.json configs C2..C5), HIP events on
+the launch stream, every call through the C ABI wrappers.  Development/reporting aid for DESIGN.md."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import aligner_amd
+from aligner_amd import synth
+dev = torch.device("cuda:0")
+
+
+def ev(fn, it=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+
+
+def lengths(B, Tx, Tymin, Tymax, seed):
+    import numpy as np
+    tx, ty = synth.synth_lengths(B, Tx, Tymin, Tymax, seed)
+    return torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+
+
+g = torch.Generator().manual_seed(0)
+# C3: full OTA pipeline [64, 512-dim text emb x 200, 80-mel x 900]
+B, Ct, Cm, Tx, Ty = 64, 512, 80, 200, 900
+params = aligner_amd.AlignmentEncoderParams.random(Ct, Cm, 80, dev, seed=3)
+text = torch.randn(B, Ct, Tx, generator=g).to(dev); mel = torch.randn(B, Cm, Ty, generator=g).to(dev)
+tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+k = aligner_amd.softattn.encode(text, params.key_proj); q = aligner_amd.softattn.encode(mel, params.query_proj)
+logp, _ = aligner_amd.soft_attention(k, q, t_x=tx)
+print("C3 [64, 512x200 text, 80x900 mel]: text encoder %.1f us, mel encoder %.1f us, similarity+log-softmax %.1f us, DP (dense path + durations) %.1f us, whole pipeline %.1f us" % (
+    ev(lambda: aligner_amd.softattn.encode(text, params.key_proj)), ev(lambda: aligner_amd.softattn.encode(mel, params.query_proj)),
+    ev(lambda: aligner_amd.soft_attention(k, q, t_x=tx)), ev(lambda: aligner_amd.align(logp, tx, ty)),
+    ev(lambda: aligner_amd.align(aligner_amd.alignment_encoder(text, mel, params, t_x=tx)[0], tx, ty))))
+# C4: one 64-utterance shard of the 512 variable-length utterances, [64, 400, 2000]
+B, Tx, Ty = 64, 400, 2000
+v = torch.from_numpy(synth.synth_value(B, Tx, Ty, 40)).to(dev)
+import numpy as np
+txa, tya = synth.synth_lengths(512, 400, 200, 2000, 4)
+tx, ty = torch.from_numpy(txa[:64].copy()).to(dev), torch.from_numpy(tya[:64].copy()).to(dev)
+print("C4 shard [64,400,2000] ragged (sum t_y = %d frames): DP durations only %.1f us, with dense fp32 path %.1f us" % (
+    int(tya[:64].sum()), ev(lambda: aligner_amd.align(v, tx, ty, want_path=False)), ev(lambda: aligner_amd.align(v, tx, ty))))
+# C5: long-form [8, 500, 4000], bf16-exact scores
+B, Tx, Ty = 8, 500, 4000
+v = torch.from_numpy(synth.synth_value(B, Tx, Ty, 5, bits=8, denom=8.0)).to(dev).to(torch.bfloat16)
+tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+print("C5 long-form [8,500,4000] bf16 scores: DP durations only %.1f us, with dense int32 path %.1f us" % (
+    ev(lambda: aligner_amd.align(v, tx, ty, want_path=False)), ev(lambda: aligner_amd.align(v, tx, ty, path_dtype=torch.int32))))
