@@ -49,6 +49,9 @@ SIGNATURES = {
     "aligner_softattn_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
     "aligner_conv1d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "aligner_conv1d_prepared_bytes": (_sz, [_i, _i, _i]),
+    "aligner_conv1d_prepare_f32": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
+    "aligner_conv1d_prepared_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aligner_forward_sum_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_forward_sum_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_beta_binomial_prior_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),

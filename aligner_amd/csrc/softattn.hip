@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "aligner_amd.h"
 #include "common.h"
@@ -792,6 +793,422 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_mfma_kernel(const float *
         }
 }
 
+// --------------------------------------------------------------------------
+// The same convolution on the bf16 matrix cores with split operands: x = hi + lo (two bf16 halves of the
+// fp32 value), product = hi*hi + hi*lo + lo*hi in fp32 accumulators -- the similarity kernel's trick,
+// ~2^-16 relative per product (far inside the 1e-4 the encoders are held to) at 16/3 times the fp32 MFMA
+// rate.  Reduction index k = (tap, in channel): one v_mfma_f32_32x32x16_bf16 k-step is one tap of 16 input
+// channels, so a chunk of 16 input channels is K k-steps.  Both operands are split once per workgroup and
+// chunk on their way into LDS, in fragment order: a fragment (8 consecutive channels of one frame / one
+// output channel) is one 16-byte LDS write and one conflict-free ds_read_b128.  Chunks are double-buffered
+// in LDS and the next chunk's global loads are in flight during the MFMAs (one barrier per chunk).
+// --------------------------------------------------------------------------
+template <int K, int WO, int WT, int AO, int AT>
+__global__ __launch_bounds__(WO * WT * 64) void conv1d_bf16x3_kernel(const float *__restrict__ x,
+                                                                       const float *__restrict__ w,
+                                                                       const float *__restrict__ bias,
+                                                                       float *__restrict__ y, int Cin, int Cout, int T,
+                                                                       int relu) {
+    constexpr int TO = 32 * WO * AO, TT = 32 * WT * AT, NTHR = WO * WT * 64;
+    constexpr int HALO = K / 2, XF = TT + 2 * HALO;
+    constexpr int XN = XF * 2;                    // x fragments per chunk: [frame][channel half]
+    constexpr int WN = K * TO * 2;                // w fragments per chunk: [tap][out channel][channel half]
+    constexpr int BUF = 2 * XN + 2 * WN;          // uint4 per buffer: Xhi, Xlo, Whi, Wlo
+    extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+    uint4 *lds = reinterpret_cast<uint4 *>(cv_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z;
+    const int o0 = blockIdx.y * TO, t0 = blockIdx.x * TT;
+    const int wo = (wave / WT) * (32 * AO), wt = (wave % WT) * (32 * AT);
+    const float *xb = x + (size_t)b * Cin * T;
+    f32x16 acc[AO][AT];
+#pragma unroll
+    for (int a = 0; a < AO; ++a)
+#pragma unroll
+        for (int c = 0; c < AT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+
+    constexpr int XTASK = (XN + NTHR - 1) / NTHR, WTASK = (WN + NTHR - 1) / NTHR;
+    float xr[XTASK][8], wr[WTASK][8];
+    // every load is unconditional (indices clamped, value masked afterwards): see and_mask()
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int j = 0; j < XTASK; ++j) {
+            int task = tid + NTHR * j;
+            task = task < XN ? task : XN - 1;
+            const int f = task >> 1, h = task & 1;
+            const int t = t0 + f - HALO;
+            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int i = i0 + 8 * h + jj;
+                const float v = xb[(size_t)(i < Cin ? i : Cin - 1) * T + tc];
+                xr[j][jj] = and_mask(v, (i < Cin && t >= 0 && t < T) ? ~0u : 0u);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WTASK; ++j) {
+            int task = tid + NTHR * j;            // tap fastest: the lanes of one output channel share two cache lines
+            task = task < WN ? task : WN - 1;
+            const int tap = task % K, rest = task / K;
+            const int h = rest & 1, o = o0 + (rest >> 1);
+            const size_t orow = (size_t)(o < Cout ? o : Cout - 1) * Cin;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int i = i0 + 8 * h + jj;
+                const float v = w[(orow + (i < Cin ? i : Cin - 1)) * K + tap];
+                wr[j][jj] = and_mask(v, (o < Cout && i < Cin) ? ~0u : 0u);
+            }
+        }
+    };
+    auto pack_split = [&](const float (&r)[8], uint4 &hi, uint4 &lo) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            __bf16 hh, ll;
+            split_bf16(r[jj], hh, ll);
+            h[jj] = hh;
+            l[jj] = ll;
+        }
+        hi = __builtin_bit_cast(uint4, h);
+        lo = __builtin_bit_cast(uint4, l);
+    };
+    auto stash = [&](uint4 *bufp) {
+#pragma unroll
+        for (int j = 0; j < XTASK; ++j) {
+            const int task = tid + NTHR * j;
+            if (task < XN) pack_split(xr[j], bufp[task], bufp[XN + task]);
+        }
+#pragma unroll
+        for (int j = 0; j < WTASK; ++j) {
+            const int task = tid + NTHR * j;
+            if (task < WN) {
+                const int tap = task % K, rest = task / K;
+                const int idx = (tap * TO + (rest >> 1)) * 2 + (rest & 1);
+                pack_split(wr[j], bufp[2 * XN + idx], bufp[2 * XN + WN + idx]);
+            }
+        }
+    };
+    fetch(0);
+    int it = 0;
+    for (int i0 = 0; i0 < Cin; i0 += 16, ++it) {
+        uint4 *bufp = lds + (it & 1) * BUF;
+        stash(bufp);                              // (the other buffer may still be read by slower waves)
+        __syncthreads();
+        if (i0 + 16 < Cin) fetch(i0 + 16);
+        const uint4 *Xhi = bufp, *Xlo = bufp + XN, *Whi = bufp + 2 * XN, *Wlo = bufp + 2 * XN + WN;
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+            bf16x8 ah[AO], al[AO], bh[AT], bl[AT];
+#pragma unroll
+            for (int a = 0; a < AO; ++a) {
+                const int idx = (tap * TO + wo + 32 * a + l31) * 2 + half;
+                ah[a] = __builtin_bit_cast(bf16x8, Whi[idx]);
+                al[a] = __builtin_bit_cast(bf16x8, Wlo[idx]);
+            }
+#pragma unroll
+            for (int c = 0; c < AT; ++c) {
+                const int idx = (wt + 32 * c + l31 + tap) * 2 + half;
+                bh[c] = __builtin_bit_cast(bf16x8, Xhi[idx]);
+                bl[c] = __builtin_bit_cast(bf16x8, Xlo[idx]);
+            }
+#pragma unroll
+            for (int a = 0; a < AO; ++a)
+#pragma unroll
+                for (int c = 0; c < AT; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[c], acc[a][c], 0, 0, 0);
+                }
+        }
+    }
+    // C/D layout: col = lane&31 (frame), row = (e&3) + 8*(e>>2) + 4*half (out channel)
+#pragma unroll
+    for (int a = 0; a < AO; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = o0 + wo + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (o >= Cout) continue;
+            const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+            for (int c = 0; c < AT; ++c) {
+                const int t = t0 + wt + 32 * c + l31;
+                if (t < T) {
+                    float v = acc[a][c][e] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[((size_t)b * Cout + o) * T + t] = v;
+                }
+            }
+        }
+}
+
+// ---- prepared weights: the split, fragment-ordered form of w, built once per weight tensor ----
+// Layout (both halves): [chunk = ceil(Cin/16)][tap][Cout padded to 128][channel half] of uint4 (8 bf16):
+// for one (chunk, tap) the fragments of consecutive output channels are contiguous, so a workgroup's
+// weight tile is K contiguous runs that it copies with coalesced 16-byte loads -- no gather, no VALU.
+// (Gathering w[o][i][tap] per workgroup cost ~300 scattered 4-byte wave-loads per chunk and CU: the
+// address coalescer, not the matrix pipe, set the pace: 466 us for the 512->1024 k=3 layer.)
+struct ConvPrep { size_t lo_off, total; int nch, cpad; };
+static ConvPrep conv_prep_layout(int Cout, int Cin, int K) {
+    ConvPrep L;
+    L.nch = (Cin + 15) / 16;
+    L.cpad = (Cout + 127) / 128 * 128;
+    const size_t half = (size_t)L.nch * K * L.cpad * 2 * sizeof(uint4);
+    L.lo_off = half;
+    L.total = 2 * half;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float *__restrict__ w, uint4 *__restrict__ phi,
+                                                        uint4 *__restrict__ plo, int Cout, int Cin, int K, int cpad,
+                                                        int nfrag) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // fragment index: ((chunk*K + tap)*cpad + o)*2 + h
+    if (idx >= nfrag) return;
+    const int h = idx & 1, o = (idx >> 1) % cpad, ct = (idx >> 1) / cpad;
+    const int tap = ct % K, ch = ct / K;
+    bf16x8 hv, lv;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int i = 16 * ch + 8 * h + jj;
+        const float v = (o < Cout && i < Cin) ? w[((size_t)o * Cin + i) * K + tap] : 0.f;
+        __bf16 hh, ll;
+        split_bf16(v, hh, ll);
+        hv[jj] = hh;
+        lv[jj] = ll;
+    }
+    phi[idx] = __builtin_bit_cast(uint4, hv);
+    plo[idx] = __builtin_bit_cast(uint4, lv);
+}
+
+// The convolution proper on prepared weights.  XV: T % 4 == 0, so the input rows can be read as aligned
+// 16-byte quads (a task = 8 channels x 4 frames -> four fragments); otherwise one frame per task.
+template <int K, int WO, int WT, int AO, int AT, bool XV>
+__global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const float *__restrict__ x,
+                                                                         const uint4 *__restrict__ phi,
+                                                                         const uint4 *__restrict__ plo,
+                                                                         const float *__restrict__ bias,
+                                                                         float *__restrict__ y, int Cin, int Cout, int T,
+                                                                         int cpad, int relu) {
+    constexpr int TO = 32 * WO * AO, TT = 32 * WT * AT, NTHR = WO * WT * 64;
+    constexpr int HALO = K / 2;
+    constexpr int F0 = XV ? 4 : HALO;             // LDS frame 0 <-> input frame t0 - F0
+    constexpr int XF = XV ? TT + 8 : TT + 2 * HALO;
+    constexpr int XN = XF * 2;                    // x fragments per chunk: [frame][channel half]
+    constexpr int WN = K * TO * 2;                // w fragments per chunk: [tap][out channel][channel half]
+    constexpr int BUF = 2 * XN + 2 * WN;          // uint4 per buffer: Xhi, Xlo, Whi, Wlo
+    extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
+    uint4 *lds = reinterpret_cast<uint4 *>(cv_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    // (an XCD-aware tile map that keeps one output tile's weights in one XCD's L2 changed nothing on the
+    // 512->1024 layer and cost 50 % on the narrow ones: not kept)
+    const int b = blockIdx.z;
+    const int o0 = blockIdx.y * TO, t0 = blockIdx.x * TT;
+    const int wo = (wave / WT) * (32 * AO), wt = (wave % WT) * (32 * AT);
+    const float *xb = x + (size_t)b * Cin * T;
+    f32x16 acc[AO][AT];
+#pragma unroll
+    for (int a = 0; a < AO; ++a)
+#pragma unroll
+        for (int c = 0; c < AT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
+
+    constexpr int WTASK = (WN + NTHR - 1) / NTHR;
+    constexpr int XQ = XV ? (XF / 4) * 2 : XN;    // x tasks per chunk
+    constexpr int XTASK = (XQ + NTHR - 1) / NTHR;
+    // one chunk's operands in registers, on their way to LDS: chunk c+1 is fetched while chunk c is multiplied
+    // (fetching two chunks ahead with two register sets was slower: 376 vs 325 us on the 512->1024 layer)
+    // (plain arrays, not a struct handed to the lambdas: that form stayed in scratch memory)
+    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // (arrays of HIP's uint4 class stayed in scratch)
+    typedef float __attribute__((ext_vector_type(4))) f32x4v;
+    u32x4 wh[WTASK], wl[WTASK];
+    f32x4v xq[XV ? XTASK : 1][8];
+    float xr[XV ? 1 : XTASK][8];
+    auto pack_split = [&](const float (&r)[8], uint4 &hi, uint4 &lo) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            __bf16 hh, ll;
+            split_bf16(r[jj], hh, ll);
+            h[jj] = hh;
+            l[jj] = ll;
+        }
+        hi = __builtin_bit_cast(uint4, h);
+        lo = __builtin_bit_cast(uint4, l);
+    };
+    auto multiply = [&](const uint4 *bufp) {
+        const uint4 *Xhi = bufp, *Xlo = bufp + XN, *Whi = bufp + 2 * XN, *Wlo = bufp + 2 * XN + WN;
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) {
+            bf16x8 ah[AO], al[AO], bh[AT], bl[AT];
+#pragma unroll
+            for (int a = 0; a < AO; ++a) {
+                const int idx = (tap * TO + wo + 32 * a + l31) * 2 + half;
+                ah[a] = __builtin_bit_cast(bf16x8, Whi[idx]);
+                al[a] = __builtin_bit_cast(bf16x8, Wlo[idx]);
+            }
+#pragma unroll
+            for (int c = 0; c < AT; ++c) {
+                const int idx = (wt + 32 * c + l31 + tap - HALO + F0) * 2 + half;
+                bh[c] = __builtin_bit_cast(bf16x8, Xhi[idx]);
+                bl[c] = __builtin_bit_cast(bf16x8, Xlo[idx]);
+            }
+#pragma unroll
+            for (int a = 0; a < AO; ++a)
+#pragma unroll
+                for (int c = 0; c < AT; ++c) {
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[c], acc[a][c], 0, 0, 0);
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[c], acc[a][c], 0, 0, 0);
+                }
+        }
+    };
+    // software pipeline, written out in the function body (as lambdas the staging arrays stayed in scratch
+    // memory): trip c stores chunk c's operands to LDS, fetches chunk c+1 into the registers, multiplies c
+    const int nch = (Cin + 15) / 16;
+    for (int cc = -1; cc < nch; ++cc) {
+        uint4 *bufp = lds + (cc & 1) * BUF;
+        if (cc >= 0) {
+        #pragma unroll
+                for (int j = 0; j < WTASK; ++j) {
+                    const int task = tid + NTHR * j;
+                    if (task < WN) {
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + task) = wh[j];
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + WN + task) = wl[j];
+            }
+                }
+                if (XV) {
+        #pragma unroll
+                    for (int j = 0; j < XTASK; ++j) {
+                        const int task = tid + NTHR * j;
+                        if (task < XQ) {
+                            const int q = task >> 1, h = task & 1;
+        #pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                float r[8];
+        #pragma unroll
+                                for (int jj = 0; jj < 8; ++jj)
+                                    r[jj] = u == 0 ? xq[j][jj].x : u == 1 ? xq[j][jj].y : u == 2 ? xq[j][jj].z : xq[j][jj].w;
+                                const int fi = (4 * q + u) * 2 + h;
+                                pack_split(r, bufp[fi], bufp[XN + fi]);
+                            }
+                        }
+                    }
+                } else {
+        #pragma unroll
+                    for (int j = 0; j < XTASK; ++j) {
+                        const int task = tid + NTHR * j;
+                        if (task < XN) pack_split(xr[j], bufp[task], bufp[XN + task]);
+                    }
+                }
+            __syncthreads();                      // (the other buffer may still be read by slower waves)
+        }
+        if (cc + 1 < nch) {
+            const int ch = cc + 1;
+                const int i0 = 16 * ch;
+        #pragma unroll
+                for (int j = 0; j < WTASK; ++j) {
+                    int task = tid + NTHR * j;
+                    task = task < WN ? task : WN - 1;
+                    const int tap = task / (TO * 2), r = task - tap * (TO * 2);
+                    const size_t src = ((size_t)(ch * K + tap) * cpad + o0) * 2 + r;
+                    wh[j] = *reinterpret_cast<const u32x4 *>(phi + src);
+                    wl[j] = *reinterpret_cast<const u32x4 *>(plo + src);
+                }
+                if (XV) {
+        #pragma unroll
+                    for (int j = 0; j < XTASK; ++j) {
+                        const int task = tid + NTHR * j;
+                        if (task < XQ) {
+                            const int q = task >> 1, h = task & 1;
+                            const int t = t0 - 4 + 4 * q;                         // aligned quad: all in or all out
+                            const bool in = t >= 0 && t < T;
+                            const int tc = t < 0 ? 0 : (t > T - 4 ? T - 4 : t);   // unconditional loads, masked afterwards
+        #pragma unroll
+                            for (int jj = 0; jj < 8; ++jj) {
+                                const int i = i0 + 8 * h + jj;
+                                const f32x4v v = *reinterpret_cast<const f32x4v *>(xb + (size_t)(i < Cin ? i : Cin - 1) * T + tc);
+                                const unsigned mk = (in && i < Cin) ? ~0u : 0u;
+                                f32x4v mv;
+                                mv.x = and_mask(v.x, mk); mv.y = and_mask(v.y, mk); mv.z = and_mask(v.z, mk); mv.w = and_mask(v.w, mk);
+                                xq[j][jj] = mv;
+                            }
+                        }
+                    }
+                } else {
+        #pragma unroll
+                    for (int j = 0; j < XTASK; ++j) {
+                        int task = tid + NTHR * j;
+                        task = task < XN ? task : XN - 1;
+                        const int f = task >> 1, h = task & 1;
+                        const int t = t0 + f - F0;
+                        const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+        #pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const int i = i0 + 8 * h + jj;
+                            const float v = xb[(size_t)(i < Cin ? i : Cin - 1) * T + tc];
+                            xr[j][jj] = and_mask(v, (i < Cin && t >= 0 && t < T) ? ~0u : 0u);
+                        }
+                    }
+                }
+        }
+        if (cc >= 0) multiply(bufp);
+    }
+    // C/D layout: col = lane&31 (frame), row = (e&3) + 8*(e>>2) + 4*half (out channel)
+#pragma unroll
+    for (int a = 0; a < AO; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = o0 + wo + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (o >= Cout) continue;
+            const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+            for (int c = 0; c < AT; ++c) {
+                const int t = t0 + wt + 32 * c + l31;
+                if (t < T) {
+                    float v = acc[a][c][e] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    y[((size_t)b * Cout + o) * T + t] = v;
+                }
+            }
+        }
+}
+
+template <int K, int WO, int WT, int AO, int AT>
+static int launch_conv_prepared(dim3 grid, hipStream_t s, const float *x, const uint4 *phi, const uint4 *plo,
+                                const float *bias, float *y, int Cin, int Cout, int T, int cpad, int relu) {
+    constexpr int TO = 32 * WO * AO, TT = 32 * WT * AT;
+    const bool xv = (T % 4) == 0;
+    const size_t xf = xv ? TT + 8 : TT + 2 * (K / 2);
+    const size_t lds = (size_t)2 * (2 * xf * 2 + 2 * K * TO * 2) * sizeof(uint4);
+    if (xv) {
+        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, true>;
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+        hipLaunchKernelGGL(kern, grid, dim3(WO * WT * 64), lds, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
+    } else {
+        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, false>;
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+        hipLaunchKernelGGL(kern, grid, dim3(WO * WT * 64), lds, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
+    }
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+template <int K, int WO, int WT, int AO, int AT>
+static int launch_conv_bf16x3(dim3 grid, hipStream_t s, const float *x, const float *w, const float *bias, float *y,
+                              int Cin, int Cout, int T, int relu) {
+    constexpr int TO = 32 * WO * AO, TT = 32 * WT * AT;
+    const size_t lds = (size_t)2 * (2 * (TT + 2 * (K / 2)) * 2 + 2 * K * TO * 2) * sizeof(uint4);
+    auto kern = conv1d_bf16x3_kernel<K, WO, WT, AO, AT>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    hipLaunchKernelGGL(kern, grid, dim3(WO * WT * 64), lds, s, x, w, bias, y, Cin, Cout, T, relu);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
 struct SaLayout { size_t hi_off, lo_off, kn_off, total; int RT, KS; };
 
 static SaLayout sa_layout(int B, int C, int Tx) {
@@ -861,6 +1278,50 @@ int aligner_softattn_f32(const float *keys, const float *queries, const int32_t 
     return multi ? launch_softattn<16, 4, true>(p, ws, L, s) : launch_softattn<16, 4, false>(p, ws, L, s);
 }
 
+size_t aligner_conv1d_prepared_bytes(int Cout, int Cin, int K) {
+    if (Cout < 1 || Cin < 1 || (K != 1 && K != 3 && K != 5)) return 0;
+    return conv_prep_layout(Cout, Cin, K).total;
+}
+
+int aligner_conv1d_prepare_f32(const float *w, void *prepared, size_t prepared_bytes, int Cout, int Cin, int K,
+                               void *stream) {
+    if (!w || !prepared) return fail(ALIGNER_EINVAL, "null pointer");
+    if (Cout < 1 || Cin < 1) return fail(ALIGNER_EINVAL, "bad shape");
+    if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    const ConvPrep L = conv_prep_layout(Cout, Cin, K);
+    if (prepared_bytes < L.total) return fail(ALIGNER_ENOSPC, "prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
+    unsigned char *pp = static_cast<unsigned char *>(prepared);
+    const int nfrag = L.nch * K * L.cpad * 2;
+    hipLaunchKernelGGL(conv_prep_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       reinterpret_cast<uint4 *>(pp), reinterpret_cast<uint4 *>(pp + L.lo_off), Cout, Cin, K, L.cpad, nfrag);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+int aligner_conv1d_prepared_f32(const float *x, const void *prepared, const float *bias, float *y, int B, int Cin,
+                                int Cout, int T, int K, int relu, void *stream) {
+    if (!x || !prepared || !y) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Cin < 1 || Cout < 1 || T < 1) return fail(ALIGNER_EINVAL, "bad shape");
+    if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    if (B == 0) return ALIGNER_OK;
+    if (B > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    const ConvPrep L = conv_prep_layout(Cout, Cin, K);
+    const unsigned char *pp = static_cast<const unsigned char *>(prepared);
+    const uint4 *phi = reinterpret_cast<const uint4 *>(pp), *plo = reinterpret_cast<const uint4 *>(pp + L.lo_off);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cout > 96) {
+        dim3 grid((T + 127) / 128, (Cout + 127) / 128, B);
+        if (grid.y > 65535) return fail(ALIGNER_EDOM, "grid too large");
+        if (K == 1) return launch_conv_prepared<1, 2, 2, 2, 2>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+        if (K == 3) return launch_conv_prepared<3, 2, 2, 2, 2>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+        return launch_conv_prepared<5, 2, 2, 2, 2>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+    }
+    dim3 grid((T + 63) / 64, 1, B);
+    if (K == 1) return launch_conv_prepared<1, 3, 2, 1, 1>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+    if (K == 3) return launch_conv_prepared<3, 3, 2, 1, 1>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+    return launch_conv_prepared<5, 3, 2, 1, 1>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, L.cpad, relu);
+}
+
 int aligner_conv1d_f32(const float *x, const float *w, const float *bias, float *y, int B, int Cin, int Cout,
                        int T, int K, int relu, void *stream) {
     if (!x || !w || !y) return fail(ALIGNER_EINVAL, "null pointer");
@@ -869,6 +1330,22 @@ int aligner_conv1d_f32(const float *x, const float *w, const float *bias, float 
     if (B > 65535) return fail(ALIGNER_EDOM, "grid too large");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    // ALIGNER_CONV_FP32=1 selects the exact-fp32 MFMA kernel (v_mfma_f32_32x32x2_f32); the default splits the
+    // operands into bf16 halves (three bf16 MFMAs per product, ~2^-16 relative)
+    static const bool exact_fp32 = [] { const char *e = getenv("ALIGNER_CONV_FP32"); return e && e[0] == '1'; }();
+    if (!exact_fp32) {
+        if (Cout > 96) {
+            dim3 grid((T + 127) / 128, (Cout + 127) / 128, B);
+            if (grid.y > 65535) return fail(ALIGNER_EDOM, "grid too large");
+            if (K == 1) return launch_conv_bf16x3<1, 2, 2, 2, 2>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+            if (K == 3) return launch_conv_bf16x3<3, 2, 2, 2, 2>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+            return launch_conv_bf16x3<5, 2, 2, 2, 2>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+        }
+        dim3 grid((T + 63) / 64, 1, B);
+        if (K == 1) return launch_conv_bf16x3<1, 3, 2, 1, 1>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+        if (K == 3) return launch_conv_bf16x3<3, 3, 2, 1, 1>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+        return launch_conv_bf16x3<5, 3, 2, 1, 1>(grid, s, x, w, bias, y, Cin, Cout, T, relu);
+    }
     if (Cout > 96) {
         dim3 grid((T + 127) / 128, (Cout + 127) / 128, B), block(256);
         if (grid.y > 65535) return fail(ALIGNER_EDOM, "grid too large");

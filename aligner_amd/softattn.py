@@ -56,6 +56,33 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if Cin2 != Cin:
         raise ValueError("channel mismatch")
     y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        # weights -> split bf16 halves in fragment order (a few microseconds), then the MFMA kernel
+        nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
+        if nprep == 0:
+            raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
+        prep = torch.empty(nprep, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K,
+                                                  _stream(x.device)))
+        _lib.check(lib.aligner_conv1d_prepared_f32(x.data_ptr(), prep.data_ptr(),
+                                                   None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                   B, Cin, Cout, T, K, int(relu), _stream(x.device)))
+    return y
+
+
+def conv1d_raw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False
+               ) -> torch.Tensor:
+    """conv1d() through aligner_conv1d_f32: raw weights, no preparation buffer (slower: every workgroup
+    splits its weight tile itself; ALIGNER_CONV_FP32=1 selects the exact-fp32 MFMA kernel)."""
+    _lib.require_gpu()
+    x = _chk(x, "x"); weight = _chk(weight, "weight")
+    bias = _chk(bias, "bias") if bias is not None else None
+    B, Cin, T = x.shape
+    Cout, Cin2, K = weight.shape
+    if Cin2 != Cin:
+        raise ValueError("channel mismatch")
+    y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().aligner_conv1d_f32(x.data_ptr(), weight.data_ptr(),
                                                   None if bias is None else bias.data_ptr(), y.data_ptr(),

@@ -175,6 +175,19 @@ int aligner_conv1d_f32(const float *x_dev, const float *w_dev, const float *bias
                        float *y_dev, int B, int Cin, int Cout, int T, int K,
                        int relu, void *stream);
 
+/*
+ * The same convolution with the weights prepared once (split into bf16 halves, in the matrix cores'
+ * fragment order): aligner_conv1d_prepare_f32 writes aligner_conv1d_prepared_bytes(Cout,Cin,K) bytes,
+ * aligner_conv1d_prepared_f32 consumes them.  Products are hi*hi + hi*lo + lo*hi in fp32 accumulators
+ * (~2^-16 relative per product).  This is the fast path of the encoders: prepare per weight update.
+ */
+size_t aligner_conv1d_prepared_bytes(int Cout, int Cin, int K);
+int aligner_conv1d_prepare_f32(const float *w_dev, void *prepared_dev, size_t prepared_bytes,
+                               int Cout, int Cin, int K, void *stream);
+int aligner_conv1d_prepared_f32(const float *x_dev, const void *prepared_dev, const float *bias_dev,
+                                float *y_dev, int B, int Cin, int Cout, int T, int K,
+                                int relu, void *stream);
+
 /* ---- the callers either side of the path (build-defined specs) ---- */
 
 /*
