@@ -1021,12 +1021,63 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
     constexpr int XTASK = (XQ + NTHR - 1) / NTHR;
     // one chunk's operands in registers, on their way to LDS: chunk c+1 is fetched while chunk c is multiplied
     // (fetching two chunks ahead with two register sets was slower: 376 vs 325 us on the 512->1024 layer)
-    // (plain arrays, not a struct handed to the lambdas: that form stayed in scratch memory)
-    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;   // (arrays of HIP's uint4 class stayed in scratch)
+    // One chunk's operands in registers on their way to LDS.  Native vector types: register arrays of HIP's
+    // uint4/float4 CLASSES stayed in scratch memory (320 instead of 201 us on the 512->1024 layer).
+    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
     typedef float __attribute__((ext_vector_type(4))) f32x4v;
-    u32x4 wh[WTASK], wl[WTASK];
-    f32x4v xq[XV ? XTASK : 1][8];
-    float xr[XV ? 1 : XTASK][8];
+    struct Stage {
+        u32x4 wh[WTASK], wl[WTASK];
+        f32x4v xq[XV ? XTASK : 1][8];
+        float xr[XV ? 1 : XTASK][8];
+    };
+    auto fetch = [&](Stage &R, int ch) {
+        const int i0 = 16 * ch;
+#pragma unroll
+        for (int j = 0; j < WTASK; ++j) {
+            int task = tid + NTHR * j;
+            task = task < WN ? task : WN - 1;
+            const int tap = task / (TO * 2), r = task - tap * (TO * 2);
+            const size_t src = ((size_t)(ch * K + tap) * cpad + o0) * 2 + r;
+            R.wh[j] = *reinterpret_cast<const u32x4 *>(phi + src);
+            R.wl[j] = *reinterpret_cast<const u32x4 *>(plo + src);
+        }
+        if (XV) {
+#pragma unroll
+            for (int j = 0; j < XTASK; ++j) {
+                const int task = tid + NTHR * j;
+                if (task < XQ) {
+                    const int q = task >> 1, h = task & 1;
+                    const int t = t0 - 4 + 4 * q;                         // aligned quad: all in or all out
+                    const bool in = t >= 0 && t < T;
+                    const int tc = t < 0 ? 0 : (t > T - 4 ? T - 4 : t);   // unconditional loads, masked afterwards
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int i = i0 + 8 * h + jj;
+                        const f32x4v v = *reinterpret_cast<const f32x4v *>(xb + (size_t)(i < Cin ? i : Cin - 1) * T + tc);
+                        const unsigned mk = (in && i < Cin) ? ~0u : 0u;
+                        f32x4v mv;
+                        mv.x = and_mask(v.x, mk); mv.y = and_mask(v.y, mk); mv.z = and_mask(v.z, mk); mv.w = and_mask(v.w, mk);
+                        R.xq[j][jj] = mv;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XTASK; ++j) {
+                int task = tid + NTHR * j;
+                task = task < XN ? task : XN - 1;
+                const int f = task >> 1, h = task & 1;
+                const int t = t0 + f - F0;
+                const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int i = i0 + 8 * h + jj;
+                    const float v = xb[(size_t)(i < Cin ? i : Cin - 1) * T + tc];
+                    R.xr[j][jj] = and_mask(v, (i < Cin && t >= 0 && t < T) ? ~0u : 0u);
+                }
+            }
+        }
+    };
     auto pack_split = [&](const float (&r)[8], uint4 &hi, uint4 &lo) {
         bf16x8 h, l;
 #pragma unroll
@@ -1066,96 +1117,51 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
                 }
         }
     };
-    // software pipeline, written out in the function body (as lambdas the staging arrays stayed in scratch
-    // memory): trip c stores chunk c's operands to LDS, fetches chunk c+1 into the registers, multiplies c
-    const int nch = (Cin + 15) / 16;
-    for (int cc = -1; cc < nch; ++cc) {
-        uint4 *bufp = lds + (cc & 1) * BUF;
-        if (cc >= 0) {
-        #pragma unroll
-                for (int j = 0; j < WTASK; ++j) {
-                    const int task = tid + NTHR * j;
-                    if (task < WN) {
-                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + task) = wh[j];
-                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + WN + task) = wl[j];
+    auto stash = [&](const Stage &R, uint4 *bufp) {
+#pragma unroll
+        for (int j = 0; j < WTASK; ++j) {
+            const int task = tid + NTHR * j;
+            if (task < WN) {
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + task) = R.wh[j];
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + WN + task) = R.wl[j];
             }
-                }
-                if (XV) {
-        #pragma unroll
-                    for (int j = 0; j < XTASK; ++j) {
-                        const int task = tid + NTHR * j;
-                        if (task < XQ) {
-                            const int q = task >> 1, h = task & 1;
-        #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                float r[8];
-        #pragma unroll
-                                for (int jj = 0; jj < 8; ++jj)
-                                    r[jj] = u == 0 ? xq[j][jj].x : u == 1 ? xq[j][jj].y : u == 2 ? xq[j][jj].z : xq[j][jj].w;
-                                const int fi = (4 * q + u) * 2 + h;
-                                pack_split(r, bufp[fi], bufp[XN + fi]);
-                            }
-                        }
-                    }
-                } else {
-        #pragma unroll
-                    for (int j = 0; j < XTASK; ++j) {
-                        const int task = tid + NTHR * j;
-                        if (task < XN) pack_split(xr[j], bufp[task], bufp[XN + task]);
-                    }
-                }
-            __syncthreads();                      // (the other buffer may still be read by slower waves)
         }
-        if (cc + 1 < nch) {
-            const int ch = cc + 1;
-                const int i0 = 16 * ch;
-        #pragma unroll
-                for (int j = 0; j < WTASK; ++j) {
-                    int task = tid + NTHR * j;
-                    task = task < WN ? task : WN - 1;
-                    const int tap = task / (TO * 2), r = task - tap * (TO * 2);
-                    const size_t src = ((size_t)(ch * K + tap) * cpad + o0) * 2 + r;
-                    wh[j] = *reinterpret_cast<const u32x4 *>(phi + src);
-                    wl[j] = *reinterpret_cast<const u32x4 *>(plo + src);
-                }
-                if (XV) {
-        #pragma unroll
-                    for (int j = 0; j < XTASK; ++j) {
-                        const int task = tid + NTHR * j;
-                        if (task < XQ) {
-                            const int q = task >> 1, h = task & 1;
-                            const int t = t0 - 4 + 4 * q;                         // aligned quad: all in or all out
-                            const bool in = t >= 0 && t < T;
-                            const int tc = t < 0 ? 0 : (t > T - 4 ? T - 4 : t);   // unconditional loads, masked afterwards
-        #pragma unroll
-                            for (int jj = 0; jj < 8; ++jj) {
-                                const int i = i0 + 8 * h + jj;
-                                const f32x4v v = *reinterpret_cast<const f32x4v *>(xb + (size_t)(i < Cin ? i : Cin - 1) * T + tc);
-                                const unsigned mk = (in && i < Cin) ? ~0u : 0u;
-                                f32x4v mv;
-                                mv.x = and_mask(v.x, mk); mv.y = and_mask(v.y, mk); mv.z = and_mask(v.z, mk); mv.w = and_mask(v.w, mk);
-                                xq[j][jj] = mv;
-                            }
-                        }
-                    }
-                } else {
-        #pragma unroll
-                    for (int j = 0; j < XTASK; ++j) {
-                        int task = tid + NTHR * j;
-                        task = task < XN ? task : XN - 1;
-                        const int f = task >> 1, h = task & 1;
-                        const int t = t0 + f - F0;
-                        const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-        #pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) {
-                            const int i = i0 + 8 * h + jj;
-                            const float v = xb[(size_t)(i < Cin ? i : Cin - 1) * T + tc];
-                            xr[j][jj] = and_mask(v, (i < Cin && t >= 0 && t < T) ? ~0u : 0u);
-                        }
+        if (XV) {
+#pragma unroll
+            for (int j = 0; j < XTASK; ++j) {
+                const int task = tid + NTHR * j;
+                if (task < XQ) {
+                    const int q = task >> 1, h = task & 1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float r[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj)
+                            r[jj] = u == 0 ? R.xq[j][jj].x : u == 1 ? R.xq[j][jj].y : u == 2 ? R.xq[j][jj].z : R.xq[j][jj].w;
+                        const int fi = (4 * q + u) * 2 + h;
+                        pack_split(r, bufp[fi], bufp[XN + fi]);
                     }
                 }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < XTASK; ++j) {
+                const int task = tid + NTHR * j;
+                if (task < XN) pack_split(R.xr[j], bufp[task], bufp[XN + task]);
+            }
         }
-        if (cc >= 0) multiply(bufp);
+    };
+    // software pipeline: chunk c+1 is fetched into registers while chunk c is multiplied out of LDS
+    // (fetching two chunks ahead with a second register set was slower: 304 vs 201 us on the 512->1024 layer)
+    const int nch = (Cin + 15) / 16;
+    Stage R;
+    fetch(R, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        uint4 *bufp = lds + (ch & 1) * BUF;
+        stash(R, bufp);                           // (the other buffer may still be read by slower waves)
+        __syncthreads();
+        if (ch + 1 < nch) fetch(R, ch + 1);
+        multiply(bufp);
     }
     // C/D layout: col = lane&31 (frame), row = (e&3) + 8*(e>>2) + 4*half (out channel)
 #pragma unroll
