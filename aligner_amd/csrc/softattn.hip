@@ -984,7 +984,7 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float *__restrict_
 
 // The convolution proper on prepared weights.  XV: T % 4 == 0, so the input rows can be read as aligned
 // 16-byte quads (a task = 8 channels x 4 frames -> four fragments); otherwise one frame per task.
-template <int K, int WO, int WT, int AO, int AT, bool XV>
+template <int K, int WO, int WT, int AO, int AT, bool XV, int SUB>
 __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const float *__restrict__ x,
                                                                          const uint4 *__restrict__ phi,
                                                                          const uint4 *__restrict__ plo,
@@ -995,8 +995,10 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
     constexpr int HALO = K / 2;
     constexpr int F0 = XV ? 4 : HALO;             // LDS frame 0 <-> input frame t0 - F0
     constexpr int XF = XV ? TT + 8 : TT + 2 * HALO;
-    constexpr int XN = XF * 2;                    // x fragments per chunk: [frame][channel half]
-    constexpr int WN = K * TO * 2;                // w fragments per chunk: [tap][out channel][channel half]
+    // a chunk = SUB sub-chunks of 16 input channels (SUB = 4 for k = 1: one tap is too little work per barrier)
+    constexpr int XN1 = XF * 2, WN1 = K * TO * 2;
+    constexpr int XN = XN1 * SUB;                 // x fragments per chunk: [sub][frame][channel half]
+    constexpr int WN = WN1 * SUB;                 // w fragments per chunk: [sub][tap][out channel][channel half]
     constexpr int BUF = 2 * XN + 2 * WN;          // uint4 per buffer: Xhi, Xlo, Whi, Wlo
     extern __shared__ __attribute__((aligned(16))) unsigned char cv_smem[];
     uint4 *lds = reinterpret_cast<uint4 *>(cv_smem);
@@ -1017,7 +1019,8 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
             for (int e = 0; e < 16; ++e) acc[a][c][e] = 0.f;
 
     constexpr int WTASK = (WN + NTHR - 1) / NTHR;
-    constexpr int XQ = XV ? (XF / 4) * 2 : XN;    // x tasks per chunk
+    constexpr int XQ1 = XV ? (XF / 4) * 2 : XN1;  // x tasks per sub-chunk
+    constexpr int XQ = XQ1 * SUB;
     constexpr int XTASK = (XQ + NTHR - 1) / NTHR;
     // one chunk's operands in registers, on their way to LDS: chunk c+1 is fetched while chunk c is multiplied
     // (fetching two chunks ahead with two register sets was slower: 376 vs 325 us on the 512->1024 layer)
@@ -1030,14 +1033,17 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
         f32x4v xq[XV ? XTASK : 1][8];
         float xr[XV ? 1 : XTASK][8];
     };
+    const int nch16 = (Cin + 15) / 16;
     auto fetch = [&](Stage &R, int ch) {
-        const int i0 = 16 * ch;
 #pragma unroll
         for (int j = 0; j < WTASK; ++j) {
             int task = tid + NTHR * j;
             task = task < WN ? task : WN - 1;
-            const int tap = task / (TO * 2), r = task - tap * (TO * 2);
-            const size_t src = ((size_t)(ch * K + tap) * cpad + o0) * 2 + r;
+            const int sub = task / WN1, t1 = task - sub * WN1;
+            const int tap = t1 / (TO * 2), r = t1 - tap * (TO * 2);
+            int c16 = ch * SUB + sub;                                     // past the last sub-chunk: any finite data
+            c16 = c16 < nch16 ? c16 : nch16 - 1;                          // (the x operand is zero there)
+            const size_t src = ((size_t)(c16 * K + tap) * cpad + o0) * 2 + r;
             R.wh[j] = *reinterpret_cast<const u32x4 *>(phi + src);
             R.wl[j] = *reinterpret_cast<const u32x4 *>(plo + src);
         }
@@ -1046,7 +1052,9 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
             for (int j = 0; j < XTASK; ++j) {
                 const int task = tid + NTHR * j;
                 if (task < XQ) {
-                    const int q = task >> 1, h = task & 1;
+                    const int sub = task / XQ1, t1 = task - sub * XQ1;
+                    const int i0 = 16 * (ch * SUB + sub);
+                    const int q = t1 >> 1, h = t1 & 1;
                     const int t = t0 - 4 + 4 * q;                         // aligned quad: all in or all out
                     const bool in = t >= 0 && t < T;
                     const int tc = t < 0 ? 0 : (t > T - 4 ? T - 4 : t);   // unconditional loads, masked afterwards
@@ -1066,7 +1074,9 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
             for (int j = 0; j < XTASK; ++j) {
                 int task = tid + NTHR * j;
                 task = task < XN ? task : XN - 1;
-                const int f = task >> 1, h = task & 1;
+                const int sub = task / XN1, t1 = task - sub * XN1;
+                const int i0 = 16 * (ch * SUB + sub);
+                const int f = t1 >> 1, h = t1 & 1;
                 const int t = t0 + f - F0;
                 const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
 #pragma unroll
@@ -1093,17 +1103,18 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
     auto multiply = [&](const uint4 *bufp) {
         const uint4 *Xhi = bufp, *Xlo = bufp + XN, *Whi = bufp + 2 * XN, *Wlo = bufp + 2 * XN + WN;
 #pragma unroll
-        for (int tap = 0; tap < K; ++tap) {
+        for (int st = 0; st < SUB * K; ++st) {
+            const int sub = st / K, tap = st - sub * K;
             bf16x8 ah[AO], al[AO], bh[AT], bl[AT];
 #pragma unroll
             for (int a = 0; a < AO; ++a) {
-                const int idx = (tap * TO + wo + 32 * a + l31) * 2 + half;
+                const int idx = sub * WN1 + (tap * TO + wo + 32 * a + l31) * 2 + half;
                 ah[a] = __builtin_bit_cast(bf16x8, Whi[idx]);
                 al[a] = __builtin_bit_cast(bf16x8, Wlo[idx]);
             }
 #pragma unroll
             for (int c = 0; c < AT; ++c) {
-                const int idx = (wt + 32 * c + l31 + tap - HALO + F0) * 2 + half;
+                const int idx = sub * XN1 + (wt + 32 * c + l31 + tap - HALO + F0) * 2 + half;
                 bh[c] = __builtin_bit_cast(bf16x8, Xhi[idx]);
                 bl[c] = __builtin_bit_cast(bf16x8, Xlo[idx]);
             }
@@ -1131,14 +1142,15 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
             for (int j = 0; j < XTASK; ++j) {
                 const int task = tid + NTHR * j;
                 if (task < XQ) {
-                    const int q = task >> 1, h = task & 1;
+                    const int sub = task / XQ1, t1 = task - sub * XQ1;
+                    const int q = t1 >> 1, h = t1 & 1;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         float r[8];
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj)
                             r[jj] = u == 0 ? R.xq[j][jj].x : u == 1 ? R.xq[j][jj].y : u == 2 ? R.xq[j][jj].z : R.xq[j][jj].w;
-                        const int fi = (4 * q + u) * 2 + h;
+                        const int fi = sub * XN1 + (4 * q + u) * 2 + h;
                         pack_split(r, bufp[fi], bufp[XN + fi]);
                     }
                 }
@@ -1153,7 +1165,7 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
     };
     // software pipeline: chunk c+1 is fetched into registers while chunk c is multiplied out of LDS
     // (fetching two chunks ahead with a second register set was slower: 304 vs 201 us on the 512->1024 layer)
-    const int nch = (Cin + 15) / 16;
+    const int nch = (Cin + 16 * SUB - 1) / (16 * SUB);
     Stage R;
     fetch(R, 0);
     for (int ch = 0; ch < nch; ++ch) {
@@ -1183,24 +1195,34 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
         }
 }
 
-template <int K, int WO, int WT, int AO, int AT>
-static int launch_conv_prepared(dim3 grid, hipStream_t s, const float *x, const uint4 *phi, const uint4 *plo,
-                                const float *bias, float *y, int Cin, int Cout, int T, int cpad, int relu) {
+template <int K, int WO, int WT, int AO, int AT, int SUB>
+static int launch_conv_prepared_sub(dim3 grid, hipStream_t s, const float *x, const uint4 *phi, const uint4 *plo,
+                                    const float *bias, float *y, int Cin, int Cout, int T, int cpad, int relu) {
     constexpr int TO = 32 * WO * AO, TT = 32 * WT * AT;
     const bool xv = (T % 4) == 0;
     const size_t xf = xv ? TT + 8 : TT + 2 * (K / 2);
-    const size_t lds = (size_t)2 * (2 * xf * 2 + 2 * K * TO * 2) * sizeof(uint4);
+    const size_t lds = (size_t)2 * SUB * (2 * xf * 2 + 2 * K * TO * 2) * sizeof(uint4);
     if (xv) {
-        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, true>;
+        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, true, SUB>;
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, grid, dim3(WO * WT * 64), lds, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
     } else {
-        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, false>;
+        auto kern = conv1d_prepared_kernel<K, WO, WT, AO, AT, false, SUB>;
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
         hipLaunchKernelGGL(kern, grid, dim3(WO * WT * 64), lds, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
     }
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
+}
+
+template <int K, int WO, int WT, int AO, int AT>
+static int launch_conv_prepared(dim3 grid, hipStream_t s, const float *x, const uint4 *phi, const uint4 *plo,
+                                const float *bias, float *y, int Cin, int Cout, int T, int cpad, int relu) {
+    // k = 1 over many input channels: 64-channel chunks (one tap of 16 channels is too little work per barrier;
+    // 1024->80 on [64,.,200]: 67 -> 36 us).  Narrow inputs keep 16-channel chunks (padding to 64 would waste them).
+    if (K == 1 && Cin >= 256)
+        return launch_conv_prepared_sub<K, WO, WT, AO, AT, (K == 1 ? 4 : 1)>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
+    return launch_conv_prepared_sub<K, WO, WT, AO, AT, 1>(grid, s, x, phi, plo, bias, y, Cin, Cout, T, cpad, relu);
 }
 
 template <int K, int WO, int WT, int AO, int AT>
