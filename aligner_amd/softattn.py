@@ -32,6 +32,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 _workspaces: dict = {}
+_prepared: dict = {}          # (weight ptr, version, shape, device) -> (prepared weights, weight)
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
@@ -58,13 +59,23 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        # weights -> split bf16 halves in fragment order (a few microseconds), then the MFMA kernel
-        nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
-        if nprep == 0:
-            raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
-        prep = torch.empty(nprep, dtype=torch.uint8, device=x.device)
-        _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K,
-                                                  _stream(x.device)))
+        # weights -> split bf16 halves in fragment order (a few microseconds), then the MFMA kernel.  The
+        # prepared form is kept per weight tensor until the tensor is modified in place (torch's version
+        # counter) or replaced.
+        key = (weight.data_ptr(), weight._version, Cout, Cin, K, x.device, _stream(x.device))   # (per stream: no cross-stream ordering)
+        prep = _prepared.get(key)
+        if prep is None:
+            nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
+            if nprep == 0:
+                raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
+            prep = torch.empty(nprep, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K,
+                                                      _stream(x.device)))
+            if len(_prepared) >= 64:
+                _prepared.clear()
+            _prepared[key] = (prep, weight)            # holding `weight` keeps its address from being reused
+        else:
+            prep = prep[0]
         _lib.check(lib.aligner_conv1d_prepared_f32(x.data_ptr(), prep.data_ptr(),
                                                    None if bias is None else bias.data_ptr(), y.data_ptr(),
                                                    B, Cin, Cout, T, K, int(relu), _stream(x.device)))
