@@ -456,6 +456,29 @@ __device__ __forceinline__ float4 load_tile_piece(const float *ub, const float *
 
 __device__ __forceinline__ unsigned absbits(float f) { return __builtin_bit_cast(unsigned, f) & 0x7FFFFFFFu; }
 
+// Finiteness scan of the loader waves: nf = maximum(|a|, |b|, |c|, |d|, nf) with gfx950's IEEE-754-2019
+// `maximum` (v_maximum3_f32 propagates NaN, unlike v_max3_f32), two issues per 16 bytes.  Afterwards
+// the scores seen so far are all finite  <=>  absbits(nf) < 0x7F800000.
+__device__ __forceinline__ void scan4(float &nf, const float4 &v) {
+    asm("v_maximum3_f32 %0, |%1|, |%2|, %0\n\tv_maximum3_f32 %0, |%3|, |%4|, %0"
+        : "+v"(nf) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+}
+
+// Buffer resource over one utterance's [Tx,Ty] fp32 block: loads take a per-lane byte offset that never
+// changes (row and column group) plus a scalar tile offset, so a tile costs the loader no address
+// arithmetic; reads past the block (last rows, last partial tile) return 0 instead of faulting.
+typedef unsigned __attribute__((ext_vector_type(4))) u32x4r;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t utterance_rsrc(const float *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    // (cast the whole vector: hipcc 7.2 turns per-component reads of the builtin's result into a
+    // one-dword load splatted over the four components)
+    const u32x4r raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const f32x4 f = __builtin_bit_cast(f32x4, raw);
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
 // Finite-score sweep of one tile: see maxpath_sweep_asm.inc (generated by tools/gen_sweep_asm.py).
 // DIAG: the tile contains cells with row == frame; `rrel` = row - first frame of the tile.
 template <bool PUBLISH, bool DIAG>
@@ -638,15 +661,34 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
                     r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
                     rowoff[k] = (unsigned)r * (unsigned)p.Ty;
                 }
-                unsigned nf = 0u;                           // max |bits| seen: >= 0x7F800000 <=> inf or NaN
+                float nf = 0.f;                             // maximum |score| seen, NaN-propagating (scan4)
                 float4 buf[DEPTH][8];
+                // VEC: buffer loads, per-lane byte offsets fixed for the whole sweep + a scalar tile offset
+                const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 4u;
+                const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
+                const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(MASKMODE == 1 ? mb : ub, ubytes);
+                unsigned voff[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) voff[k] = (rowoff[k] + 4u * (unsigned)cg) * 4u;
                 // every refill is issued unconditionally (tile index clamped to t_hi: duplicates hit
                 // L2) so the number of loads in flight at each register->LDS pass is a constant
                 auto issue = [&](float4 (&dst)[8], int t) {
                     const int tc = t < t_hi ? t : t_hi;
+                    if (VEC) {
+                        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(TC * tc * 4);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        dst[k] = load_tile_piece<VEC, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
+                        for (int k = 0; k < 8; ++k) {
+                            dst[k] = buffer_load4(urs, voff[k], soff);
+                            if (MASKMODE == 1) {
+                                const float4 mk = buffer_load4(mrs, voff[k], soff);
+                                dst[k].x *= mk.x; dst[k].y *= mk.y; dst[k].z *= mk.z; dst[k].w *= mk.w;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            dst[k] = load_tile_piece<false, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
+                    }
                 };
 #pragma unroll
                 for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
@@ -657,19 +699,24 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
                         const int t = t_lo + i0 + d;
                         if (t <= t_hi) {
                             float *dst = mytiles + (t & 1) * 64 * TILE_LD;
+                            if (t == ntb - 1) {
+                                // frames >= t_y (mel padding, or past the row's end) never matter: zero them
+                                const int c0 = TC * t + 4 * cg;
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                float4 v = buf[d][k];
-                                if (t == ntb - 1) {                 // frames >= t_y (mel padding) never matter: zero them
-                                    const int c0 = TC * t + 4 * cg;
+                                for (int k = 0; k < 8; ++k) {
+                                    float4 v = buf[d][k];
                                     v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
                                     v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
+                                    *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                    scan4(nf, v);
                                 }
-                                *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
-                                const unsigned a = absbits(v.x), bb = absbits(v.y), c = absbits(v.z), dd = absbits(v.w);
-                                const unsigned ab = a > bb ? a : bb, cd = c > dd ? c : dd;
-                                const unsigned mx = ab > cd ? ab : cd;
-                                nf = nf > mx ? nf : mx;
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    const float4 v = buf[d][k];
+                                    *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                    scan4(nf, v);
+                                }
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -678,7 +725,7 @@ __global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathPara
                         if (t <= t_hi) __syncthreads();
                     }
                 }
-                if (nf >= 0x7F800000u) flagp[0] = 1;        // benign race: every writer stores 1
+                if (absbits(nf) >= 0x7F800000u) flagp[0] = 1;   // benign race: every writer stores 1
                 for (int i = 0; i < ntb + NW - w - t_hi - 1; ++i) __syncthreads();
             } else {
                 for (int i = 0; i < ntb + NW; ++i) __syncthreads();
@@ -1149,8 +1196,10 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     p.stamps = g_debug_stamps;
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
     const size_t lds_max = (size_t)lds_limit();
+    // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
-                     (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
+                     (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
+                     (size_t)Tx * (size_t)Ty * 4 < (1ull << 31);
 
     // halo-lane kernel (opt-in: measured on par with the 63-rows-per-wave kernel at [64,200,1000] --
     // 5 instead of 6 issues per frame and a 3x faster table-driven backtrack, but 7 instead of 4
