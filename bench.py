@@ -308,7 +308,7 @@ def main():
         # same command, gfx950 correction applied; see the note in the file) -- not measured by this run
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")) as f:
                 traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
         except (OSError, ValueError, KeyError):
             traffic = None
