@@ -126,6 +126,26 @@ def test_random_shapes_vs_oracle(dev):
             _check_consistency(p, tok, dur, tx, ty)
 
 
+@pytest.mark.parametrize("shape", [(3, 200, 1004), (2, 64, 100), (4, 127, 420), (1, 253, 996), (5, 300, 332)])
+def test_vector_loader_tail_tiles(dev, shape):
+    """16-byte loader path (Ty % 4 == 0) with a last tile that runs past the row end and, for the last
+    rows of an utterance, past its [Tx,Ty] block: the loaders' buffer loads must neither fault nor let
+    what they read there (the next row, the next utterance, zeros) reach the result."""
+    B, Tx, Ty = shape
+    rng = np.random.default_rng(Tx * 1000 + Ty)
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    v[-1] = np.inf                                   # poison everything the last utterance must not read ...
+    tx = np.full(B, Tx, np.int32)
+    ty = np.full(B, Ty, np.int32)
+    tx[-1], ty[-1] = max(1, Tx // 3), max(Tx // 3, Ty // 2)
+    v[-1, :tx[-1], :ty[-1]] = rng.standard_normal((tx[-1], ty[-1])).astype(np.float32)   # ... except its own cells
+    want = _oracle_path(v, tx, ty)
+    for kw in ({}, {"force_generic": True}):
+        p, tok, dur = _hip(v, tx, ty, dev, **kw)
+        assert np.array_equal(p, want), kw
+        _check_consistency(p, tok, dur, tx, ty)
+
+
 def test_wide_text_uses_generic_path(dev):
     """Tx > 512 is outside the pipelined kernel; the generic kernel must take over."""
     rng = np.random.default_rng(9)
