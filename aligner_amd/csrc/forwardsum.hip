@@ -32,6 +32,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <type_traits>
 
 #include "aligner_amd.h"
 #include "common.h"
@@ -76,6 +78,22 @@ __device__ __forceinline__ float fs_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
+}
+
+// the same maximum without LDS traffic (__shfl_xor is a ds_bpermute: ~100 cycles a step): the usual DPP
+// ladder, result in lane 63, broadcast through an SGPR
+__device__ __forceinline__ float fs_wave_max_dpp(float v) {
+#define FS_DPP_MAX(CTRL, RMASK)                                                                          \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),       \
+                                                                        __builtin_bit_cast(int, v), CTRL, RMASK, 0xf, false)))
+    FS_DPP_MAX(0xB1, 0xf);      // quad_perm [1,0,3,2]
+    FS_DPP_MAX(0x4E, 0xf);      // quad_perm [2,3,0,1]
+    FS_DPP_MAX(0x141, 0xf);     // row_half_mirror
+    FS_DPP_MAX(0x140, 0xf);     // row_mirror
+    FS_DPP_MAX(0x142, 0xa);     // row_bcast:15 into rows 1 and 3
+    FS_DPP_MAX(0x143, 0xc);     // row_bcast:31 into rows 2 and 3
+#undef FS_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // lane i <- src[lane i-1]; lane 0 gets `edge`          (wave_shr:1, bound_ctrl off keeps `old`)
@@ -336,6 +354,265 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_backward_kernel(FwdSumParam
     }
 }
 
+// --------------------------------------------------------------------------
+// Systolic form for T_text <= 252 (the usual TTS range): FOUR sweeping waves instead of one.
+//
+// One wave with R = 4 rows per lane spends ~530 cycles per frame, most of it waiting on its own
+// exp2 -> log2 chains.  Here wave w owns text rows 63w .. 63w+62, one per lane, and the four waves form
+// the same tile pipeline as the path search (maxpath.hip): in phase p wave w sweeps tile p-1-w of SY_TW
+// frames, a ghost lane replays the neighbouring wave's boundary row (forward: lane 0 = row 63w-1, read
+// from the upper wave's alpha tile; backward: lane 63 = row 63w+63, read from the lower wave's g tile),
+// one barrier per tile.  Waves 4..7 stage: stager w moves wave w's tiles.
+//
+// Each wave keeps its OWN running offset (C_w forward, D_w backward; per-wave drift and re-basing keep
+// every row block near 0 whatever the others do), so a boundary value travels with its wave's offset
+// of that frame and is converted on arrival:  ghost = value + float(C_sender[y] - C_receiver[y]).
+// The workspace holds one offset per (wave, frame); posterior = exp2(alpha + beta + C_w[y] + D_w[y] - log Z).
+// --------------------------------------------------------------------------
+constexpr int SY_NW = 4, SY_TW = 16, SY_LD = 68;   // waves, frames per tile, floats per frame row (64 + pad)
+constexpr int SY_THREADS = 2 * SY_NW * 64;
+constexpr int SY_TILE = SY_TW * SY_LD;            // floats per tile buffer
+
+__global__ __launch_bounds__(SY_THREADS) void fwdsum_forward_sys_kernel(FwdSumParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tin = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
+    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha
+    double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & (SY_NW - 1);
+    const bool sweeper = wave < SY_NW;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    double *offs = p.offs + ((size_t)b * SY_NW + w) * p.NT;
+    if (!(tx >= 1 && tx <= ty)) {                             // no monotonic alignment exists: loss = +inf
+        if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
+        if (!sweeper) for (int t = lane; t < p.NT; t += 64) offs[t] = 0.0;
+        return;
+    }
+    const int ntl = (ty + SY_TW - 1) / SY_TW;
+    const int row = 63 * w + lane - 1;                        // sweeper: lane 0 is the ghost (row 63w-1)
+    float prev = (w == 0 && lane == 0) ? 0.f : FS_NEG;        // row -1 is log 1 before the first frame
+    const bool ghost = lane == 0, rowok = row < tx;
+    float drift = 0.f;
+    double C = 0.0, drift_d = 0.0;
+    for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        if (!sweeper) {
+            const int tl = ph - w, ts = ph - 2 - w;
+            if (tl >= 0 && tl < ntl) {
+                // unconditional loads (row and frame clamped into the utterance), whole tile in flight
+                float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
+                const int y0 = tl * SY_TW;
+                float v[SY_TW];
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
+                    int rg = 63 * w + r - 1;
+                    rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
+                    const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                    v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                }
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    dst[c * SY_LD + r] = fs_in(v[i]);
+                }
+            }
+            if (ts >= 0 && ts < ntl) {
+                const float *src = tout + (w * 2 + (ts & 1)) * SY_TILE;
+                const int y0 = ts * SY_TW;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    const int rg = 63 * w + r - 1;
+                    if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                }
+                if (lane < SY_TW && y0 + lane < ty) offs[y0 + lane] = toff[(w * 2 + (ts & 1)) * SY_TW + lane];
+            }
+        } else {
+            const int t = ph - 1 - w;
+            if (t >= 0 && t < ntl) {
+                const int y0 = t * SY_TW, buf = t & 1;
+                const float *src = tin + (w * 2 + buf) * SY_TILE + lane;
+                float *dst = tout + (w * 2 + buf) * SY_TILE + lane;
+                double *myoff = toff + (w * 2 + buf) * SY_TW;
+                // the wave above: its last row's alpha (slot 63) and its offsets of the same frames
+                const float *ring = tout + (((w ? w - 1 : 0) * 2 + buf) * SY_TILE) + 63;
+                const double *cp = toff + ((w ? w - 1 : 0) * 2 + buf) * SY_TW;
+                double Ck = 0.0;                              // lane c keeps C of frame c: one store per tile
+                auto frames = [&](auto tail) {
+                    constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+                    for (int c = 0; c < SY_TW; ++c) {
+                        const int y = y0 + c;
+                        const float lp = src[c * SY_LD];
+                        const float up = fs_from_lane_below(FS_NEG, prev);
+                        const float v = fs_lae2(prev, up) + (lp - drift);
+                        C += drift_d;
+                        float a = (rowok && (!TAIL || y < ty)) ? v : FS_NEG;
+                        if (w != 0) {                                                // uniform
+                            const float gh = fmaxf(ring[c * SY_LD] + (float)(cp[c] - C), FS_NEG);
+                            a = ghost ? gh : a;
+                        } else {
+                            a = ghost ? FS_NEG : a;
+                        }
+                        Ck = (lane == c) ? C : Ck;
+                        dst[c * SY_LD] = a;
+                        prev = a;
+                        if (TAIL && y == ty - 1) {                                   // uniform
+                            if (row == tx - 1 && !ghost) {
+                                const double lz = (double)a + C;                     // log2 Z
+                                p.logz[b] = lz;
+                                p.loss[b] = (float)(-lz * FS_LN2);
+                            }
+                        }
+                        if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                            // re-base this wave's running column on its maximum and learn the per-frame drift
+                            float m = fs_wave_max_dpp(prev);
+                            if (m < 0.5f * FS_NEG) m = 0.f;                          // an all-"log 0" column
+                            C += (double)m;
+                            drift += m * (1.0f / FS_RB);
+                            drift_d = (double)drift;
+                            prev = fmaxf(prev - m, FS_NEG);
+                        }
+                    }
+                };
+                if (y0 + SY_TW < ty) frames(std::false_type{});
+                else                 frames(std::true_type{});
+                if (lane < SY_TW) myoff[lane] = Ck;
+            }
+        }
+        fs_lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumParams p) {
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tlp = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
+    float *tal = tlp + SY_NW * 2 * SY_TILE;                   // alpha (relative to C_w)
+    float *tgr = tal + SY_NW * 2 * SY_TILE;                   // gradient out
+    float *tg = tgr + SY_NW * 2 * SY_TILE;                    // g = beta + logp (relative to D_w): slot 0 feeds the wave above
+    double *toff = reinterpret_cast<double *>(tg + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    double *tdof = toff + SY_NW * 2 * SY_TW;                  // [NW][2][TW] D_w per frame
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
+    const bool sweeper = wave < SY_NW;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0;
+    // frames past the utterance's last tile (everything when no alignment exists): gradient 0
+    for (int r = 0; r < p.Tx; ++r)
+        for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
+    if (!ok) return;
+    const double logz = p.logz[b];
+    const double *offs = p.offs + ((size_t)b * SY_NW + w) * p.NT;
+    const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
+    float g_prev = FS_NEG;                                    // beta[x,y+1] + logp[x,y+1], relative to D
+    const bool ghost = lane == 63, rowok = row < tx;
+    float drift = 0.f;
+    double D = 0.0, Dl = -logz, drift_d = 0.0;                // Dl = D - log Z
+    for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        if (!sweeper) {
+            const int kl = ph - wr, ks = ph - 2 - wr;         // tile counted from the end
+            if (kl >= 0 && kl < ntl) {
+                const int t = ntl - 1 - kl, y0 = t * SY_TW;
+                float *dlp = tlp + (w * 2 + (kl & 1)) * SY_TILE, *dal = tal + (w * 2 + (kl & 1)) * SY_TILE;
+                float v[SY_TW], u[SY_TW];
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    int rg = 63 * w + r;
+                    rg = rg < tx ? rg : tx - 1;
+                    const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                    v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                    u[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+                }
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    dlp[c * SY_LD + r] = fs_in(v[i]);
+                    dal[c * SY_LD + r] = u[i];
+                }
+                if (lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? offs[y0 + lane] : 0.0;
+            }
+            if (ks >= 0 && ks < ntl) {
+                const float *src = tgr + (w * 2 + (ks & 1)) * SY_TILE;
+                const int y0 = (ntl - 1 - ks) * SY_TW;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    const int rg = 63 * w + r;
+                    if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                }
+            }
+        } else {
+            const int k = ph - 1 - wr;
+            if (k >= 0 && k < ntl) {
+                const int buf = k & 1, y0 = (ntl - 1 - k) * SY_TW;
+                const float *slp = tlp + (w * 2 + buf) * SY_TILE + lane, *sal = tal + (w * 2 + buf) * SY_TILE + lane;
+                float *dgr = tgr + (w * 2 + buf) * SY_TILE + lane, *dg = tg + (w * 2 + buf) * SY_TILE + lane;
+                const double *myoff = toff + (w * 2 + buf) * SY_TW;
+                double *mydof = tdof + (w * 2 + buf) * SY_TW;
+                // the wave below: its first row's g (slot 0) and its D offsets of the same frames
+                const int wb = w + 1 < SY_NW ? w + 1 : w;
+                const float *ring = tg + (wb * 2 + buf) * SY_TILE;
+                const double *dp = tdof + (wb * 2 + buf) * SY_TW;
+                double Dk = 0.0;                              // lane c keeps D of frame c
+                auto frames = [&](auto tail) {
+                    constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+                    for (int c = SY_TW - 1; c >= 0; --c) {
+                        const int y = y0 + c;
+                        if (TAIL && y >= ty) {                                       // uniform: padding frames
+                            dgr[c * SY_LD] = 0.f;
+                            continue;
+                        }
+                        const float lp = slp[c * SY_LD], al = sal[c * SY_LD];
+                        const float st = (float)(myoff[c] + Dl);                     // C_w[y] + D_w - log Z, uniform
+                        const float dn = fs_from_lane_above(FS_NEG, g_prev);          // row below
+                        float beta;
+                        if (TAIL && y == ty - 1) beta = (row == tx - 1) ? 0.f : FS_NEG;   // uniform branch
+                        else                     beta = fs_lae2(g_prev, dn);
+                        beta = rowok ? beta : FS_NEG;
+                        dgr[c * SY_LD] = -__builtin_amdgcn_exp2f(al + beta + st);     // 2^(-1e30) = 0
+                        float g = fmaxf(beta + (lp - drift), FS_NEG);
+                        D += drift_d;
+                        Dl += drift_d;
+                        if (w + 1 < SY_NW) {                                         // uniform
+                            const float gh = fmaxf(ring[c * SY_LD] + (float)(dp[c] - D), FS_NEG);
+                            g = ghost ? gh : g;
+                        } else {
+                            g = ghost ? FS_NEG : g;
+                        }
+                        dg[c * SY_LD] = g;
+                        Dk = (lane == c) ? D : Dk;
+                        g_prev = g;
+                        if ((c & (FS_RB - 1)) == 0) {
+                            float m = fs_wave_max_dpp(g_prev);
+                            if (m < 0.5f * FS_NEG) m = 0.f;
+                            D += (double)m;
+                            Dl += (double)m;
+                            drift += m * (1.0f / FS_RB);
+                            drift_d = (double)drift;
+                            g_prev = fmaxf(g_prev - m, FS_NEG);
+                        }
+                    }
+                };
+                if (k != 0) frames(std::false_type{});
+                else        frames(std::true_type{});
+                if (lane < SY_TW) mydof[lane] = Dk;
+            }
+        }
+        fs_lds_barrier();
+    }
+}
+
 struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, R; };
 
 static FsLayout fs_layout(int B, int Tx, int Ty) {
@@ -344,7 +621,7 @@ static FsLayout fs_layout(int B, int Tx, int Ty) {
     L.NT = Ty;                                    // one offset per frame
     L.alpha_off = 0;
     L.offs_off = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
-    L.logz_off = L.offs_off + align_up((size_t)B * L.NT * sizeof(double), 256);
+    L.logz_off = L.offs_off + align_up((size_t)B * SY_NW * L.NT * sizeof(double), 256);   // per (wave, frame)
     L.total = L.logz_off + align_up((size_t)B * sizeof(double), 256);
     return L;
 }
@@ -362,6 +639,20 @@ static int fs_launch(const FwdSumParams &p, bool backward, hipStream_t s) {
     if (backward) {
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
         hipLaunchKernelGGL(kb, dim3(p.B), dim3(FS_THREADS), lds_b, s, p);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    return ALIGNER_OK;
+}
+
+static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
+    const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double);
+    const size_t lds_b = (size_t)4 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double);
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fwdsum_forward_sys_kernel), lds_f));
+    hipLaunchKernelGGL(fwdsum_forward_sys_kernel, dim3(p.B), dim3(SY_THREADS), lds_f, s, p);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    if (backward) {
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fwdsum_backward_sys_kernel), lds_b));
+        hipLaunchKernelGGL(fwdsum_backward_sys_kernel, dim3(p.B), dim3(SY_THREADS), lds_b, s, p);
         ALIGNER_HIP_CHECK(hipGetLastError());
     }
     return ALIGNER_OK;
@@ -393,6 +684,7 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
                    loss_out, grad_out, B, Tx, Ty, L.NT};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
+    if (Tx <= 63 * SY_NW && !getenv("ALIGNER_FWDSUM_ONE_WAVE")) return fs_launch_sys(p, bwd, s);
     if (L.R == 4) return fs_launch<4>(p, bwd, s);
     if (L.R == 8) return fs_launch<8>(p, bwd, s);
     return fs_launch<16>(p, bwd, s);
