@@ -442,22 +442,23 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_forward_sys_kernel(FwdSumPa
                 const float *ring = tout + (((w ? w - 1 : 0) * 2 + buf) * SY_TILE) + 63;
                 const double *cp = toff + ((w ? w - 1 : 0) * 2 + buf) * SY_TW;
                 double Ck = 0.0;                              // lane c keeps C of frame c: one store per tile
+                // the whole tile's operands up front (one LDS latency per tile, not one per frame)
+                float lpv[SY_TW], rgv[SY_TW];
+                double cpv[SY_TW];
+#pragma unroll
+                for (int c = 0; c < SY_TW; ++c) { lpv[c] = src[c * SY_LD]; rgv[c] = ring[c * SY_LD]; cpv[c] = cp[c]; }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
                     for (int c = 0; c < SY_TW; ++c) {
                         const int y = y0 + c;
-                        const float lp = src[c * SY_LD];
+                        const float lp = lpv[c];
                         const float up = fs_from_lane_below(FS_NEG, prev);
                         const float v = fs_lae2(prev, up) + (lp - drift);
                         C += drift_d;
                         float a = (rowok && (!TAIL || y < ty)) ? v : FS_NEG;
-                        if (w != 0) {                                                // uniform
-                            const float gh = fmaxf(ring[c * SY_LD] + (float)(cp[c] - C), FS_NEG);
-                            a = ghost ? gh : a;
-                        } else {
-                            a = ghost ? FS_NEG : a;
-                        }
+                        const float gh = (w != 0) ? fmaxf(rgv[c] + (float)(cpv[c] - C), FS_NEG) : FS_NEG;
+                        a = ghost ? gh : a;
                         Ck = (lane == c) ? C : Ck;
                         dst[c * SY_LD] = a;
                         prev = a;
@@ -564,6 +565,14 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumP
                 const float *ring = tg + (wb * 2 + buf) * SY_TILE;
                 const double *dp = tdof + (wb * 2 + buf) * SY_TW;
                 double Dk = 0.0;                              // lane c keeps D of frame c
+                // the whole tile's operands up front (one LDS latency per tile, not one per frame)
+                float lpv[SY_TW], alv[SY_TW], rgv[SY_TW];
+                double cov[SY_TW], dpv[SY_TW];
+#pragma unroll
+                for (int c = 0; c < SY_TW; ++c) {
+                    lpv[c] = slp[c * SY_LD]; alv[c] = sal[c * SY_LD]; rgv[c] = ring[c * SY_LD];
+                    cov[c] = myoff[c]; dpv[c] = dp[c];
+                }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
@@ -573,8 +582,8 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumP
                             dgr[c * SY_LD] = 0.f;
                             continue;
                         }
-                        const float lp = slp[c * SY_LD], al = sal[c * SY_LD];
-                        const float st = (float)(myoff[c] + Dl);                     // C_w[y] + D_w - log Z, uniform
+                        const float lp = lpv[c], al = alv[c];
+                        const float st = (float)(cov[c] + Dl);                       // C_w[y] + D_w - log Z, uniform
                         const float dn = fs_from_lane_above(FS_NEG, g_prev);          // row below
                         float beta;
                         if (TAIL && y == ty - 1) beta = (row == tx - 1) ? 0.f : FS_NEG;   // uniform branch
@@ -584,12 +593,8 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumP
                         float g = fmaxf(beta + (lp - drift), FS_NEG);
                         D += drift_d;
                         Dl += drift_d;
-                        if (w + 1 < SY_NW) {                                         // uniform
-                            const float gh = fmaxf(ring[c * SY_LD] + (float)(dp[c] - D), FS_NEG);
-                            g = ghost ? gh : g;
-                        } else {
-                            g = ghost ? FS_NEG : g;
-                        }
+                        const float gh = (w + 1 < SY_NW) ? fmaxf(rgv[c] + (float)(dpv[c] - D), FS_NEG) : FS_NEG;
+                        g = ghost ? gh : g;
                         dg[c * SY_LD] = g;
                         Dk = (lane == c) ? D : Dk;
                         g_prev = g;
