@@ -102,11 +102,20 @@ def dev():
     return torch.device("cuda:0")
 
 
+# T_text <= 252 takes the four-wave systolic kernels (wave boundaries at rows 63, 126, 189), wider text the
+# one-wave kernels; `one_wave` forces the latter on the small shapes as well
 @gpu
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("B,Tx,Ty,ragged", [(3, 7, 19, True), (4, 64, 200, True), (2, 200, 1000, False),
-                                             (2, 300, 700, True), (1, 520, 900, True), (2, 33, 33, False)])
-def test_forward_sum_matches_oracle(dev, B, Tx, Ty, ragged):
+                                             (2, 300, 700, True), (1, 520, 900, True), (2, 33, 33, False),
+                                             (3, 63, 150, True), (3, 127, 333, True), (2, 189, 190, False),
+                                             (3, 190, 401, True), (2, 252, 640, True), (2, 253, 500, True)])
+def test_forward_sum_matches_oracle(dev, monkeypatch, B, Tx, Ty, ragged, one_wave):
     import aligner_amd
+    if one_wave:
+        if Tx > 252:
+            pytest.skip("already the one-wave kernel")
+        monkeypatch.setenv("ALIGNER_FWDSUM_ONE_WAVE", "1")
     rng = np.random.default_rng(B * 1000 + Tx)
     lp = _rand_logp(rng, B, Tx, Ty)
     if ragged:
