@@ -369,11 +369,14 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_backward_kernel(FwdSumParam
 // of that frame and is converted on arrival:  ghost = value + float(C_sender[y] - C_receiver[y]).
 // The workspace holds one offset per (wave, frame); posterior = exp2(alpha + beta + C_w[y] + D_w[y] - log Z).
 // --------------------------------------------------------------------------
-constexpr int SY_NW = 4, SY_TW = 16, SY_LD = 68;   // waves, frames per tile, floats per frame row (64 + pad)
-constexpr int SY_THREADS = 2 * SY_NW * 64;
-constexpr int SY_TILE = SY_TW * SY_LD;            // floats per tile buffer
+constexpr int SY_LD = 68;                          // floats per frame row of a tile (64 lanes + pad)
+constexpr int SY_NW_MAX = 8;                       // offsets in the workspace: one per (wave, frame)
+// NW sweeping waves (T_text <= 63 NW) and TW frames per tile: <4, 16> up to 252 rows, <8, 8> up to 504 (the
+// 16-wave workgroup has 128 VGPRs per lane and the backward kernel four tile arrays in LDS)
 
-__global__ __launch_bounds__(SY_THREADS) void fwdsum_forward_sys_kernel(FwdSumParams p) {
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdSumParams p) {
+    constexpr int SY_TILE = SY_TW * SY_LD;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     float *tin = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
     float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_forward_sys_kernel(FwdSumPa
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    double *offs = p.offs + ((size_t)b * SY_NW + w) * p.NT;
+    double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     if (!(tx >= 1 && tx <= ty)) {                             // no monotonic alignment exists: loss = +inf
         if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
         if (!sweeper) for (int t = lane; t < p.NT; t += 64) offs[t] = 0.0;
@@ -489,7 +492,9 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_forward_sys_kernel(FwdSumPa
     }
 }
 
-__global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumParams p) {
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(FwdSumParams p) {
+    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     float *tlp = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
     float *tal = tlp + SY_NW * 2 * SY_TILE;                   // alpha (relative to C_w)
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(SY_THREADS) void fwdsum_backward_sys_kernel(FwdSumP
         for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
     if (!ok) return;
     const double logz = p.logz[b];
-    const double *offs = p.offs + ((size_t)b * SY_NW + w) * p.NT;
+    const double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
     float g_prev = FS_NEG;                                    // beta[x,y+1] + logp[x,y+1], relative to D
     const bool ghost = lane == 63, rowok = row < tx;
@@ -626,7 +631,7 @@ static FsLayout fs_layout(int B, int Tx, int Ty) {
     L.NT = Ty;                                    // one offset per frame
     L.alpha_off = 0;
     L.offs_off = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
-    L.logz_off = L.offs_off + align_up((size_t)B * SY_NW * L.NT * sizeof(double), 256);   // per (wave, frame)
+    L.logz_off = L.offs_off + align_up((size_t)B * SY_NW_MAX * L.NT * sizeof(double), 256);   // per (wave, frame)
     L.total = L.logz_off + align_up((size_t)B * sizeof(double), 256);
     return L;
 }
@@ -649,15 +654,19 @@ static int fs_launch(const FwdSumParams &p, bool backward, hipStream_t s) {
     return ALIGNER_OK;
 }
 
+template <int SY_NW, int SY_TW>
 static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
+    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
     const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double);
     const size_t lds_b = (size_t)4 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double);
-    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fwdsum_forward_sys_kernel), lds_f));
-    hipLaunchKernelGGL(fwdsum_forward_sys_kernel, dim3(p.B), dim3(SY_THREADS), lds_f, s, p);
+    auto kf = fwdsum_forward_sys_kernel<SY_NW, SY_TW>;
+    auto kb = fwdsum_backward_sys_kernel<SY_NW, SY_TW>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
+    hipLaunchKernelGGL(kf, dim3(p.B), dim3(SY_THREADS), lds_f, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     if (backward) {
-        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fwdsum_backward_sys_kernel), lds_b));
-        hipLaunchKernelGGL(fwdsum_backward_sys_kernel, dim3(p.B), dim3(SY_THREADS), lds_b, s, p);
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
+        hipLaunchKernelGGL(kb, dim3(p.B), dim3(SY_THREADS), lds_b, s, p);
         ALIGNER_HIP_CHECK(hipGetLastError());
     }
     return ALIGNER_OK;
@@ -689,7 +698,10 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
                    loss_out, grad_out, B, Tx, Ty, L.NT};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
-    if (Tx <= 63 * SY_NW && !getenv("ALIGNER_FWDSUM_ONE_WAVE")) return fs_launch_sys(p, bwd, s);
+    if (!getenv("ALIGNER_FWDSUM_ONE_WAVE")) {
+        if (Tx <= 63 * 4) return fs_launch_sys<4, 16>(p, bwd, s);
+        if (Tx <= 63 * 8) return fs_launch_sys<8, 8>(p, bwd, s);
+    }
     if (L.R == 4) return fs_launch<4>(p, bwd, s);
     if (L.R == 8) return fs_launch<8>(p, bwd, s);
     return fs_launch<16>(p, bwd, s);

@@ -102,18 +102,19 @@ def dev():
     return torch.device("cuda:0")
 
 
-# T_text <= 252 takes the four-wave systolic kernels (wave boundaries at rows 63, 126, 189), wider text the
-# one-wave kernels; `one_wave` forces the latter on the small shapes as well
+# T_text <= 252 / 504 takes the four- / eight-wave systolic kernels (wave boundaries every 63 rows), wider
+# text the one-wave kernels; `one_wave` forces the latter on the small shapes as well
 @gpu
 @pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("B,Tx,Ty,ragged", [(3, 7, 19, True), (4, 64, 200, True), (2, 200, 1000, False),
                                              (2, 300, 700, True), (1, 520, 900, True), (2, 33, 33, False),
                                              (3, 63, 150, True), (3, 127, 333, True), (2, 189, 190, False),
-                                             (3, 190, 401, True), (2, 252, 640, True), (2, 253, 500, True)])
+                                             (3, 190, 401, True), (2, 252, 640, True), (2, 253, 500, True), (2, 379, 800, True),
+                                             (1, 504, 1100, False), (1, 505, 700, True)])
 def test_forward_sum_matches_oracle(dev, monkeypatch, B, Tx, Ty, ragged, one_wave):
     import aligner_amd
     if one_wave:
-        if Tx > 252:
+        if Tx > 504:
             pytest.skip("already the one-wave kernel")
         monkeypatch.setenv("ALIGNER_FWDSUM_ONE_WAVE", "1")
     rng = np.random.default_rng(B * 1000 + Tx)

@@ -51,3 +51,12 @@ v = torch.from_numpy(synth.synth_value(B, Tx, Ty, 5, bits=8, denom=8.0)).to(dev)
 tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
 print("C5 long-form [8,500,4000] bf16 scores: DP durations only %.1f us, with dense int32 path %.1f us" % (
     ev(lambda: aligner_amd.align(v, tx, ty, want_path=False)), ev(lambda: aligner_amd.align(v, tx, ty, path_dtype=torch.int32))))
+# widened rows at the C2 and C5 shapes
+for (B, Tx, Ty, Cc) in ((64, 200, 1000, 512), (8, 500, 4000, 512)):
+    lp = torch.log_softmax(torch.randn(B, Tx, Ty, generator=g), dim=1).to(dev)
+    tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+    dur = aligner_amd.align(lp, tx, ty, want_path=False).durations
+    h = torch.randn(B, Cc, Tx, generator=g).to(dev)
+    print("[%d,%d,%d]: forward-sum loss %.1f us, with gradient %.1f us, beta-binomial prior %.1f us, length regulator (C=%d) %.1f us" % (
+        B, Tx, Ty, ev(lambda: aligner_amd.forward_sum(lp, tx, ty, want_grad=False)), ev(lambda: aligner_amd.forward_sum(lp, tx, ty)),
+        ev(lambda: aligner_amd.beta_binomial_prior(tx, ty, Tx, Ty)), Cc, ev(lambda: aligner_amd.regulate(h, dur, Ty))))
