@@ -251,6 +251,35 @@ struct WalkChunk<KMIN, KMIN, CHECK> {
     }
 };
 
+// Decision words of `ntw` tiles, rows [0, rows_used), from the workspace into the LDS window: 16-byte loads,
+// eight in flight per thread (one element at a time this copy was a memory round trip per 4 bytes and a
+// quarter of the long-form kernel's time).  rows_used and ROWS are multiples of 64; the window's row
+// stride RP is odd (bank spread for the walk), hence the four 4-byte LDS stores.
+__device__ __forceinline__ void load_window(unsigned *win, int RP, const unsigned *gbits, int ROWS, int rows_used,
+                                            int ntw, int tid, int nthreads) {
+    typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+    const int q = rows_used >> 2, n4 = ntw * q;
+    for (int base = 0; base < n4; base += 8 * nthreads) {
+        u32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int idx = base + k * nthreads + tid;
+            idx = idx < n4 ? idx : n4 - 1;
+            const int j = idx / q, r4 = idx - j * q;
+            v[k] = *reinterpret_cast<const u32x4 *>(gbits + (size_t)j * ROWS + 4 * r4);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int idx = base + k * nthreads + tid;
+            if (idx < n4) {
+                const int j = idx / q, r4 = idx - j * q;
+                unsigned *d = win + j * RP + 4 * r4;
+                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthreads = blockDim.x;
@@ -277,10 +306,7 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
     if (single) {
         if (!in_lds) {
             __syncthreads();
-            for (int idx = tid; idx < ntb * rows_used; idx += nthreads) {
-                const int j = idx / rows_used, r = idx - j * rows_used;
-                win[j * RP + r] = gbits[(size_t)j * p.ROWS + r];
-            }
+            load_window(win, RP, gbits, p.ROWS, rows_used, ntb, tid, nthreads);
             __syncthreads();
         }
         ALIGNER_STAMP(2);
@@ -305,10 +331,7 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
         const int ntw = jhi - jb;
         if (!in_lds) {
             __syncthreads();                           // previous window fully consumed
-            for (int idx = tid; idx < ntw * rows_used; idx += nthreads) {
-                const int j = idx / rows_used, r = idx - j * rows_used;
-                win[j * RP + r] = gbits[(size_t)(jb + j) * p.ROWS + r];
-            }
+            load_window(win, RP, gbits + (size_t)jb * p.ROWS, p.ROWS, rows_used, ntw, tid, nthreads);
             __syncthreads();
         }
         ALIGNER_STAMP(2);
