@@ -342,19 +342,33 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
             unsigned w1 = (x >= 2) ? wrow[x - 1] : 0u;          // row x-1 (prefetch)
             while (x >= 1) {
                 const unsigned w2 = (x >= 3) ? wrow[x - 2] : 0u;    // row x-2: two rows of LDS latency cover
-                int jr = (e >> 5) - jb;                             // window-relative tile of frame e
-                if (jr < 0) break;                                  // row x continues in an earlier window
-                unsigned mw = 0u;
-                if (jr < ntw) {
-                    const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w0, jr);
-                    mw = word & (0xFFFFFFFFu << ((~e) & (TC - 1)));
-                } else {
-                    jr = ntw;                                       // e lies past this window: every word qualifies
-                }
-                int s;
-                if (mw != 0u) {
-                    s = (((jb + jr) << 5) | (TC - 1)) - __builtin_ctz(mw);
-                } else {
+                // common case in one scalar statement: e's own word lies in this window and holds a decision
+                // bit at or before e (jr = window-relative tile of frame e; an unsigned compare also rejects
+                // jr < 0)
+                int s, ok, jr, jrc, valid, t, word;
+                asm volatile(
+                    "s_lshr_b32 %[jr], %[e], 5\n\t"
+                    "s_sub_i32 %[jr], %[jr], %[jb]\n\t"
+                    "s_not_b32 %[t], %[e]\n\t"
+                    "s_or_b32 %[s], %[e], 31\n\t"                   // last frame of e's tile
+                    "s_cmp_lt_u32 %[jr], %[ntw]\n\t"
+                    "s_cselect_b32 %[jrc], %[jr], 0\n\t"
+                    "s_cselect_b32 %[valid], -1, 0\n\t"
+                    "s_lshl_b32 %[t], -1, %[t]\n\t"                 // frames <= e  <->  bits >= 31 - (e & 31)
+                    "v_readlane_b32 %[word], %[w], %[jrc]\n\t"
+                    "s_and_b32 %[t], %[t], %[valid]\n\t"
+                    "s_and_b32 %[word], %[word], %[t]\n\t"
+                    "s_cselect_b32 %[ok], 1, 0\n\t"
+                    "s_ff1_i32_b32 %[t], %[word]\n\t"               // lowest set bit = latest such frame
+                    "s_sub_i32 %[s], %[s], %[t]\n\t"
+                    : [jr] "=&s"(jr), [t] "=&s"(t), [s] "=&s"(s), [jrc] "=&s"(jrc), [valid] "=&s"(valid),
+                      [word] "=&s"(word), [ok] "=&s"(ok)
+                    : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [jb] "s"(__builtin_amdgcn_readfirstlane(jb)),
+                      [ntw] "s"(__builtin_amdgcn_readfirstlane(ntw)), [w] "v"(w0)
+                    : "scc");
+                if (__builtin_amdgcn_readfirstlane(ok) == 0) {
+                    if (jr < 0) break;                              // row x continues in an earlier window
+                    if (jr > ntw) jr = ntw;                         // e lies past this window: every word qualifies
                     const unsigned long long bal = __ballot(lane < jr && w0 != 0u);
                     if (bal == 0ull) break;                         // start lies in an earlier window
                     const int js = 63 - __builtin_clzll(bal);
