@@ -97,11 +97,26 @@ __global__ __launch_bounds__(256) void regulate_kernel(const float *__restrict__
         }
         tok = lo;
     }
-    if (tok_out) tok_out[(size_t)b * Ty + y] = tok;
+    if (tok_out && blockIdx.z == 0) tok_out[(size_t)b * Ty + y] = tok;
     if (out) {
-        const float *hb = h + (size_t)b * C * Tx;
+        // this workgroup's slice of the channels (gridDim.z slices), eight gathers in flight per thread.
+        // The loads are unconditional (token clamped) and masked afterwards: a select fed by a load is
+        // compiled to "load, wait, select", one memory round trip per element.
+        const int cpz = (C + gridDim.z - 1) / gridDim.z;
+        const int c0 = blockIdx.z * cpz, c1 = (c0 + cpz < C) ? c0 + cpz : C;
+        const unsigned keep = (tok >= 0) ? 0xFFFFFFFFu : 0u;
+        const int tc = tok >= 0 ? tok : 0;
+        const float *hb = h + (size_t)b * C * Tx + tc;
         float *ob = out + (size_t)b * C * Ty + y;
-        for (int c = 0; c < C; ++c) ob[(size_t)c * Ty] = (tok >= 0) ? hb[(size_t)c * Tx + tok] : 0.f;
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(unsigned, hb[(size_t)(c + i) * Tx]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ob[(size_t)(c + i) * Ty] = __builtin_bit_cast(float, v[i] & keep);
+        }
+        for (; c < c1; ++c) ob[(size_t)c * Ty] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hb[(size_t)c * Tx]) & keep);
     }
 }
 
@@ -132,7 +147,13 @@ int aligner_regulate_f32(const float *h, const int32_t *durations, float *out, i
     if (B > 65535) return fail(ALIGNER_EDOM, "B=%d too large", B);
     if ((size_t)(Tx + 256) * sizeof(int) > 60 * 1024) return fail(ALIGNER_EDOM, "Tx=%d too large", Tx);
     if (B == 0) return ALIGNER_OK;
-    dim3 grid((Ty + 255) / 256, B);
+    // channel slices: enough workgroups to keep every CU's memory queue busy (>= ~8 per CU)
+    int nz = 1;
+    if (out) {
+        const long wgs = (long)((Ty + 255) / 256) * B;
+        while (nz < 16 && wgs * nz < 2048 && C / (nz * 2) >= 16) nz *= 2;
+    }
+    dim3 grid((Ty + 255) / 256, B, nz);
     hipLaunchKernelGGL(regulate_kernel, grid, dim3(256), (size_t)(Tx + 256) * sizeof(int),
                        static_cast<hipStream_t>(stream), h, durations, out, tok_out, C, Tx, Ty);
     ALIGNER_HIP_CHECK(hipGetLastError());
