@@ -26,14 +26,15 @@ namespace aligner {
 // three lgamma per frame, two logs and one exp per cell, all in double (fp32 lgamma near 2000 is off
 // by 1e-3, i.e. 0.1 % of the pmf).
 __global__ __launch_bounds__(256) void prior_kernel(const int *__restrict__ t_xs, const int *__restrict__ t_ys,
-                                                    float *__restrict__ prior, int Tx, int Ty, double scaling) {
-    extern __shared__ double logfact[];                      // lgamma(k+1), k = 0..n
+                                                    float *__restrict__ prior, int Tx, int Ty, double scaling,
+                                                    int ktab) {
+    extern __shared__ double logfact[];                      // lgamma(k+1), k = 0..max(n, ktab)
     const int b = blockIdx.y;
     const int y = blockIdx.x * 256 + threadIdx.x;
     int n = t_xs[b], ty = t_ys[b];
     n = n < 0 ? 0 : (n > Tx ? Tx : n);
     ty = ty < 0 ? 0 : (ty > Ty ? Ty : ty);
-    for (int k = threadIdx.x; k <= n; k += 256) logfact[k] = lgamma((double)k + 1.0);
+    for (int k = threadIdx.x; k <= (n > ktab ? n : ktab); k += 256) logfact[k] = lgamma((double)k + 1.0);
     __syncthreads();
     if (y >= Ty) return;
     float *out = prior + (size_t)b * Tx * Ty + y;
@@ -42,6 +43,18 @@ __global__ __launch_bounds__(256) void prior_kernel(const int *__restrict__ t_xs
         return;
     }
     const double a = scaling * (double)(y + 1), bb = scaling * (double)(ty - y);
+    if (ktab > 0) {
+        // integer scaling (the usual 1.0): a and b are integers, every lgamma is a log-factorial out of the
+        // LDS table (filled up to n + s*(t_y + 1) by the caller's choice of `ktab`): no log in the cell loop
+        const int ia = (int)a, ib = (int)bb;
+        const double frame = logfact[n] - logfact[n + ia + ib - 1] - logfact[ia - 1] - logfact[ib - 1] + logfact[ia + ib - 1];
+        for (int x = 0; x < n; ++x) {
+            const double lp = frame - logfact[x] - logfact[n - x] + logfact[x + ia - 1] + logfact[n - x + ib - 1];
+            out[(size_t)x * Ty] = (float)exp(lp);
+        }
+        for (int x = n; x < Tx; ++x) out[(size_t)x * Ty] = 0.f;
+        return;
+    }
     const double frame = logfact[n] - lgamma((double)n + a + bb) - lgamma(a) - lgamma(bb) + lgamma(a + bb);
     double l1 = lgamma(a);                                   // lgamma(x + a) at x = 0
     double l2 = lgamma((double)n + bb);                      // lgamma(n - x + b) at x = 0
@@ -134,8 +147,18 @@ int aligner_beta_binomial_prior_f32(const int32_t *t_xs, const int32_t *t_ys, fl
     if ((size_t)(Tx + 1) * sizeof(double) > 60 * 1024) return fail(ALIGNER_EDOM, "Tx=%d too large", Tx);
     if (B == 0) return ALIGNER_OK;
     dim3 grid((Ty + 255) / 256, B);
-    hipLaunchKernelGGL(prior_kernel, grid, dim3(256), (size_t)(Tx + 1) * sizeof(double), static_cast<hipStream_t>(stream),
-                       t_xs, t_ys, prior_out, Tx, Ty, (double)scaling);
+    // integer scaling: log-factorial table up to Tx + s*(Ty + 1) in LDS if it fits, else the lgamma recurrence
+    int ktab = 0;
+    size_t lds = (size_t)(Tx + 1) * sizeof(double);
+    if (scaling == std::floor(scaling) && scaling >= 1.f) {
+        const double top = (double)Tx + (double)scaling * ((double)Ty + 1.0) + 1.0;
+        if ((top + 1.0) * sizeof(double) <= 60.0 * 1024) {
+            ktab = (int)top;
+            lds = (size_t)(ktab + 1) * sizeof(double);
+        }
+    }
+    hipLaunchKernelGGL(prior_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream),
+                       t_xs, t_ys, prior_out, Tx, Ty, (double)scaling, ktab);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }

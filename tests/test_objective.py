@@ -173,7 +173,7 @@ def test_forward_sum_is_an_upper_bound_of_the_best_path(dev):
 
 
 @gpu
-@pytest.mark.parametrize("scaling", [1.0, 0.5])
+@pytest.mark.parametrize("scaling", [1.0, 0.5, 2.0])
 def test_prior_matches_scipy(dev, scaling):
     import aligner_amd
     tx, ty = np.array([37, 200, 1]), np.array([300, 1000, 5])
