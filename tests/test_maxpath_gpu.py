@@ -146,6 +146,30 @@ def test_vector_loader_tail_tiles(dev, shape):
         _check_consistency(p, tok, dur, tx, ty)
 
 
+def test_long_utterances_windowed_backtrack(dev):
+    """T_mel > 2048: more than 64 tiles of decision words, so the backtrack runs over several windows read
+    back from the workspace.  Ragged lengths, ties and long tokens (rows that span a window boundary)."""
+    rng = np.random.default_rng(77)
+    for it, (B, Tx, Ty) in enumerate([(3, 120, 2500), (2, 300, 4100), (4, 64, 3000), (2, 500, 2080), (3, 30, 6200)]):
+        if it % 2 == 0:
+            v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+        else:
+            v = rng.integers(-2, 3, (B, Tx, Ty)).astype(np.float32)       # heavy ties
+        # a few rows that are strongly preferred for thousands of frames: tokens longer than a window
+        for b in range(B):
+            r = int(rng.integers(0, Tx))
+            v[b, r, :] += 3.0
+        ty = rng.integers(Ty // 2, Ty + 1, B).astype(np.int32)
+        ty[0] = Ty
+        tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
+        tx[0] = Tx
+        want = _oracle_path(v, tx, ty)
+        for kw in ({}, {"force_generic": True}):
+            p, tok, dur = _hip(v, tx, ty, dev, **kw)
+            assert np.array_equal(p, want), (it, kw)
+            _check_consistency(p, tok, dur, tx, ty)
+
+
 def test_wide_text_uses_generic_path(dev):
     """Tx > 512 is outside the pipelined kernel; the generic kernel must take over."""
     rng = np.random.default_rng(9)
