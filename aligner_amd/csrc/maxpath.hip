@@ -251,6 +251,78 @@ struct WalkChunk<KMIN, KMIN, CHECK> {
     }
 };
 
+// The same row step for a WINDOW of tiles [jb, jb + ntw) (decision words in the workspace, more than 64
+// tiles): lane = window-relative tile.  Rows are still static (wr[K] = row xbase+K), the window is not:
+// a row whose frame e lies below the window, or whose start is not in it, sets `stop` and the walk resumes
+// at that row in the next (earlier) window; a frame e above the window (a token that spans the boundary)
+// means every word of the window qualifies.
+template <int K>
+__device__ __forceinline__ void walk_row_window(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
+                                                int lane, int jb, int ntw, int &stop) {
+    const int xr = xbase + K;
+    if (stop == 0 && xr <= x && xr >= 1) {                       // uniform; rows above x are done already
+        const unsigned w = wr[K];
+        int s, ok, jr, jrc, valid, t, word;
+        asm volatile(
+            "s_lshr_b32 %[jr], %[e], 5\n\t"
+            "s_sub_i32 %[jr], %[jr], %[jb]\n\t"                   // window-relative tile of frame e
+            "s_not_b32 %[t], %[e]\n\t"
+            "s_or_b32 %[s], %[e], 31\n\t"                         // last frame of e's tile
+            "s_cmp_lt_u32 %[jr], %[ntw]\n\t"                      // inside the window (unsigned: also jr >= 0)
+            "s_cselect_b32 %[jrc], %[jr], 0\n\t"
+            "s_cselect_b32 %[valid], -1, 0\n\t"
+            "s_lshl_b32 %[t], -1, %[t]\n\t"                       // frames <= e  <->  bits >= 31 - (e & 31)
+            "v_readlane_b32 %[word], %[w], %[jrc]\n\t"
+            "s_and_b32 %[t], %[t], %[valid]\n\t"
+            "s_and_b32 %[word], %[word], %[t]\n\t"                // SCC = a decision bit at or before e in e's word
+            "s_cselect_b32 %[ok], 1, 0\n\t"
+            "s_ff1_i32_b32 %[t], %[word]\n\t"
+            "s_sub_i32 %[s], %[s], %[t]\n\t"
+            : [jr] "=&s"(jr), [t] "=&s"(t), [s] "=&s"(s), [jrc] "=&s"(jrc), [valid] "=&s"(valid),
+              [word] "=&s"(word), [ok] "=&s"(ok)
+            : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [jb] "s"(__builtin_amdgcn_readfirstlane(jb)),
+              [ntw] "s"(__builtin_amdgcn_readfirstlane(ntw)), [w] "v"(w)
+            : "scc");
+        if (__builtin_amdgcn_readfirstlane(ok) == 0) {
+            if (jr < 0) {
+                stop = 1;                                        // row xr continues in an earlier window
+            } else {
+                if (jr > ntw) jr = ntw;                          // e lies past this window: every word qualifies
+                const unsigned long long bal = __ballot(lane < jr && w != 0u);
+                if (bal == 0ull) {
+                    stop = 1;                                    // its start lies in an earlier window
+                } else {
+                    const int js = 63 - __builtin_clzll(bal);
+                    const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w, js);
+                    s = (((jb + js) << 5) | (TC - 1)) - __builtin_ctz(wsel);
+                }
+            }
+        }
+        if (stop == 0) {
+            s = __builtin_amdgcn_readfirstlane(s);
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(startv) : "s"(s), "n"(K));   // row xr owns [s, e]
+            e = __builtin_amdgcn_readfirstlane(s - 1);
+            x = xr - 1;
+        }
+    }
+}
+
+template <int K, int KMIN>
+struct WalkChunkW {
+    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
+                                               int lane, int jb, int ntw, int &stop) {
+        walk_row_window<K>(wr, xbase, x, e, startv, lane, jb, ntw, stop);
+        WalkChunkW<K - 1, KMIN>::run(wr, xbase, x, e, startv, lane, jb, ntw, stop);
+    }
+};
+template <int KMIN>
+struct WalkChunkW<KMIN, KMIN> {
+    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
+                                               int lane, int jb, int ntw, int &stop) {
+        walk_row_window<KMIN>(wr, xbase, x, e, startv, lane, jb, ntw, stop);
+    }
+};
+
 // Decision words of `ntw` tiles, rows [0, rows_used), from the workspace into the LDS window: 16-byte loads,
 // eight in flight per thread (one element at a time this copy was a memory round trip per 4 bytes and a
 // quarter of the long-form kernel's time).  rows_used and ROWS are multiples of 64; the window's row
@@ -335,54 +407,17 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
             __syncthreads();
         }
         ALIGNER_STAMP(2);
-        if (walker) {
+        if (walker && x >= 1) {
             // lanes past the window read tile 0's words; they can never be selected (lane < jr <= ntw)
             const unsigned *wrow = win + (lane < ntw ? lane : 0) * RP;
-            unsigned w0 = (x >= 1) ? wrow[x] : 0u;              // words of row x
-            unsigned w1 = (x >= 2) ? wrow[x - 1] : 0u;          // row x-1 (prefetch)
-            while (x >= 1) {
-                const unsigned w2 = (x >= 3) ? wrow[x - 2] : 0u;    // row x-2: two rows of LDS latency cover
-                // common case in one scalar statement: e's own word lies in this window and holds a decision
-                // bit at or before e (jr = window-relative tile of frame e; an unsigned compare also rejects
-                // jr < 0)
-                int s, ok, jr, jrc, valid, t, word;
-                asm volatile(
-                    "s_lshr_b32 %[jr], %[e], 5\n\t"
-                    "s_sub_i32 %[jr], %[jr], %[jb]\n\t"
-                    "s_not_b32 %[t], %[e]\n\t"
-                    "s_or_b32 %[s], %[e], 31\n\t"                   // last frame of e's tile
-                    "s_cmp_lt_u32 %[jr], %[ntw]\n\t"
-                    "s_cselect_b32 %[jrc], %[jr], 0\n\t"
-                    "s_cselect_b32 %[valid], -1, 0\n\t"
-                    "s_lshl_b32 %[t], -1, %[t]\n\t"                 // frames <= e  <->  bits >= 31 - (e & 31)
-                    "v_readlane_b32 %[word], %[w], %[jrc]\n\t"
-                    "s_and_b32 %[t], %[t], %[valid]\n\t"
-                    "s_and_b32 %[word], %[word], %[t]\n\t"
-                    "s_cselect_b32 %[ok], 1, 0\n\t"
-                    "s_ff1_i32_b32 %[t], %[word]\n\t"               // lowest set bit = latest such frame
-                    "s_sub_i32 %[s], %[s], %[t]\n\t"
-                    : [jr] "=&s"(jr), [t] "=&s"(t), [s] "=&s"(s), [jrc] "=&s"(jrc), [valid] "=&s"(valid),
-                      [word] "=&s"(word), [ok] "=&s"(ok)
-                    : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [jb] "s"(__builtin_amdgcn_readfirstlane(jb)),
-                      [ntw] "s"(__builtin_amdgcn_readfirstlane(ntw)), [w] "v"(w0)
-                    : "scc");
-                if (__builtin_amdgcn_readfirstlane(ok) == 0) {
-                    if (jr < 0) break;                              // row x continues in an earlier window
-                    if (jr > ntw) jr = ntw;                         // e lies past this window: every word qualifies
-                    const unsigned long long bal = __ballot(lane < jr && w0 != 0u);
-                    if (bal == 0ull) break;                         // start lies in an earlier window
-                    const int js = 63 - __builtin_clzll(bal);
-                    const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w0, js);
-                    s = (((jb + js) << 5) | (TC - 1)) - __builtin_ctz(wsel);
-                }
-                s = __builtin_amdgcn_readfirstlane(s);
-                // row x owns frames [s, e]  (core.pyx:33-35)
-                startv = (lane == (x & 63)) ? s : startv;
-                if ((x & 63) == 0) startsL[x + lane] = startv;      // chunk complete: one LDS store
-                e = __builtin_amdgcn_readfirstlane(s - 1);
-                x = __builtin_amdgcn_readfirstlane(x - 1);
-                w0 = w1;
-                w1 = w2;
+            int stop = 0;
+            for (int c = x >> 6; c >= 0 && stop == 0; --c) {
+                unsigned wr[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) wr[k] = wrow[64 * c + k];      // 64 rows x (lane = window tile)
+                WalkChunkW<63, 0>::run(wr, 64 * c, x, e, startv, lane, jb, ntw, stop);
+                // chunk finished (a stopped one is finished from the next window; startv carries over)
+                if (stop == 0) startsL[64 * c + lane] = startv;
             }
         }
     }
