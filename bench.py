@@ -234,6 +234,7 @@ def main():
         gathered = [torch.empty((world * args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
 
     copied = [None] * nstreams                 # per stream: its durations were copied out (N>1)
+    copied_ev = [torch.cuda.Event() for _ in range(nstreams)]    # re-recorded every step: no per-step allocation
 
     def run(nsteps: int):
         ge = args.gather_every
@@ -253,7 +254,7 @@ def main():
                 if slot == 0 and done[bi] is not None:
                     cur.wait_event(done[bi])               # bucket bi's previous gather has read it
                 buckets[bi][slot].copy_(steps[k].dur, non_blocking=True)
-                copied[k] = torch.cuda.Event()
+                copied[k] = copied_ev[k]
                 copied[k].record(cur)
                 if slot == ge - 1 or i == nsteps - 1:
                     comm_stream.wait_stream(cur)
