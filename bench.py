@@ -57,7 +57,9 @@ class Step:
         self.ws = torch.zeros(nws + 256, dtype=torch.uint8, device=dev)
         self.sa_ws = torch.empty(self.lib.aligner_softattn_workspace_bytes(B, C_ATT, TX) + 256, dtype=torch.uint8,
                                  device=dev)
+        self.dur_out = self.dur          # where the DP kernel writes the durations (N>1: a slot of a gather bucket)
         self.graph = None
+        self.slot_graphs = {}            # N>1: one captured step per bucket slot this stream serves
         self.use_graph = use_graph
 
     def stream(self) -> int:
@@ -71,7 +73,7 @@ class Step:
 
     def forward(self):
         _lib.check(self.lib.aligner_maxpath_forward_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(),
-                                                        self.t_y.data_ptr(), self.tok.data_ptr(), self.dur.data_ptr(),
+                                                        self.t_y.data_ptr(), self.tok.data_ptr(), self.dur_out.data_ptr(),
                                                         self.ws.data_ptr(), self.ws.numel(), B, TX, TY, -1e9, 0,
                                                         self.stream()))
 
@@ -103,6 +105,24 @@ class Step:
             print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); using eager launches",
                   file=sys.stderr)
             self.graph = None
+
+    def capture_slot(self, key, dur_slot: torch.Tensor):
+        """N>1: the same step with the durations written straight into `dur_slot` (a row of a gather
+        bucket), so that no per-step copy (and no per-step host work beyond one graph launch) is needed."""
+        self.dur_out = dur_slot
+        self.capture()
+        self.slot_graphs[key] = (self.graph, dur_slot)
+        self.dur_out = self.dur
+        self.graph = None
+
+    def run_slot(self, key):
+        g, dur_slot = self.slot_graphs[key]
+        if g is not None:
+            g.replay()
+        else:
+            self.dur_out = dur_slot
+            self.eager()
+            self.dur_out = self.dur
 
     def __call__(self):
         if self.graph is not None:
@@ -192,7 +212,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if args.gpus > 1 or world > 1:
+    # ALIGNER_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, duration buckets) with one rank
+    if args.gpus > 1 or world > 1 or os.environ.get("ALIGNER_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -220,44 +241,45 @@ def main():
         with torch.cuda.stream(strm):
             st.eager()
     torch.cuda.synchronize(dev)
+    # duration gather (N>1): double-buffered buckets of `ge` steps, all-gathered over RCCL on a side
+    # stream so the exchange overlaps the next bucket's compute.  The DP kernel of step i writes its
+    # durations straight into buckets[(i // ge) % 2][i % ge]: one captured graph per (bucket, slot), `ge`
+    # a multiple of the number of streams so that a slot always belongs to the same stream.  Per step the
+    # host only launches a graph, as in the single-GPU run.
+    comm_stream = torch.cuda.Stream(dev) if dist is not None else None
+    buckets = gathered = None
+    done = [None, None]
+    ge = args.gather_every
+    if dist is not None:
+        ge = max(nstreams, (ge + nstreams - 1) // nstreams * nstreams)
+        buckets = [torch.zeros((ge, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * ge, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
+        for bi in range(2):
+            for slot in range(ge):
+                steps[slot % nstreams].capture_slot((bi, slot), buckets[bi][slot])
+        torch.cuda.synchronize(dev)
     for st in steps:
         st.capture()
     step = steps[0]
 
-    # duration gather (N>1): double-buffered buckets of `gather_every` steps, all-gathered over
-    # RCCL on a side stream so the exchange overlaps the next bucket's compute
-    comm_stream = torch.cuda.Stream(dev) if dist is not None else None
-    buckets = gathered = None
-    done = [None, None]
-    if dist is not None:
-        buckets = [torch.empty((args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world * args.gather_every, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
-
-    copied = [None] * nstreams                 # per stream: its durations were copied out (N>1)
-    copied_ev = [torch.cuda.Event() for _ in range(nstreams)]    # re-recorded every step: no per-step allocation
-
     def run(nsteps: int):
-        ge = args.gather_every
         main = torch.cuda.current_stream(dev)
         for strm in streams:
             strm.wait_stream(main)
-        for i in range(nsteps):
-            k = i % nstreams
-            if copied[k] is not None:
-                streams[k].wait_event(copied[k])       # the bucket copy still reads this stream's durations
-            with torch.cuda.stream(streams[k]):
-                steps[k]()
-            if dist is not None:
-                main.wait_stream(streams[k])
-                bi, slot = (i // ge) % 2, i % ge
-                cur = main
-                if slot == 0 and done[bi] is not None:
-                    cur.wait_event(done[bi])               # bucket bi's previous gather has read it
-                buckets[bi][slot].copy_(steps[k].dur, non_blocking=True)
-                copied[k] = copied_ev[k]
-                copied[k].record(cur)
+        if dist is None:
+            for i in range(nsteps):
+                with torch.cuda.stream(streams[i % nstreams]):
+                    steps[i % nstreams]()
+        else:
+            for i in range(nsteps):
+                k, bi, slot = i % nstreams, (i // ge) % 2, i % ge
+                if slot < nstreams and done[bi] is not None:
+                    streams[k].wait_event(done[bi])        # bucket bi's previous gather has read it
+                with torch.cuda.stream(streams[k]):
+                    steps[k].run_slot((bi, slot))
                 if slot == ge - 1 or i == nsteps - 1:
-                    comm_stream.wait_stream(cur)
+                    for strm in streams:
+                        comm_stream.wait_stream(strm)
                     with torch.cuda.stream(comm_stream):
                         dist.all_gather_into_tensor(gathered[bi], buckets[bi])
                         ev = torch.cuda.Event()
@@ -287,7 +309,14 @@ def main():
 
     # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
     for st in steps:
-        assert int(st.dur.sum().item()) == B * TY and bool((st.tok[:, -1] == TX - 1).all())
+        assert bool((st.tok[:, -1] == TX - 1).all())
+        if dist is None:
+            assert int(st.dur.sum().item()) == B * TY
+    if dist is not None:
+        filled = min(args.steps + args.warmup, ge)
+        for bi in range(2):
+            sums = buckets[bi].sum(dim=(1, 2))
+            assert bool(((sums == B * TY) | (sums == 0)).all()) and (bi == 1 or int((sums == B * TY).sum()) >= min(filled, ge))
 
     if rank == 0:
         n = max(world, 1)
@@ -334,7 +363,7 @@ def main():
                        "launch": "hipGraph" if step.graph is not None else "eager",
                        "batches_in_flight": nstreams,
                        "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
-                                                               f"{args.gather_every} steps" if n > 1 else "")},
+                                                               f"{ge} steps" if n > 1 else "")},
             "roofline": roofline,
         }
         if n == 1 and not args.no_cpu_baseline:
