@@ -98,3 +98,16 @@ def test_product_never_imports_the_oracle():
                                 or "libmaxpath_oracle" in line:
                             bad.append((fn, line.strip()))
     assert not bad, bad
+
+
+def test_generated_sweep_asm_is_in_sync(tmp_path):
+    """aligner_amd/csrc/maxpath_sweep_asm.inc is generated (tools/gen_sweep_asm.py) and committed: the
+    committed text must be what the generator writes."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_sweep_asm", os.path.join(ROOT, "tools", "gen_sweep_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(gen.OUT).read()
+    gen.OUT = str(tmp_path / "maxpath_sweep_asm.inc")
+    gen.main()
+    assert open(gen.OUT).read() == committed
