@@ -638,7 +638,7 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 }
 
 template <int NW, int DEPTH, bool VEC, int MASKMODE>
-__global__ __launch_bounds__(NW * 128) void maxpath_pipelined_kernel(MaxpathParams p) {
+__global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_kernel(MaxpathParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1322,7 +1322,7 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
                 switch (NW) {
                     case 1: return launch_pipelined<1, 4>(p, vec, maskmode, lds, s);
                     case 2: return launch_pipelined<2, 4>(p, vec, maskmode, lds, s);
-                    case 4: return launch_pipelined<4, 4>(p, vec, maskmode, lds, s);
+                    case 4: return launch_pipelined<4, 2>(p, vec, maskmode, lds, s);
                     default: return launch_pipelined<8, 2>(p, vec, maskmode, lds, s);
                 }
             }
