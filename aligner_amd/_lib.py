@@ -45,6 +45,7 @@ SIGNATURES = {
     "aligner_maxpath_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "aligner_maxpath_read_status": (_i, [_vp, _vp, _vp]),
     "aligner_debug_set_stamps": (None, [_vp]),
+    "aligner_debug_set_option": (_i, [_c.c_char_p, _i]),
     "aligner_maxpath_host_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
     "aligner_softattn_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
@@ -98,3 +99,32 @@ def require_gpu() -> None:
     if lib.aligner_device_count() < 1:
         raise RuntimeError("aligner_amd needs an AMD GPU (gfx950): no HIP device is visible and "
                            "there is deliberately no CPU fallback")
+
+
+class StreamWorkspaces:
+    """Scratch buffers for the C-ABI calls, one per (device, stream).
+
+    Every entry point is asynchronous on the caller's current stream and its workspace holds
+    live state between the launches of one call (token starts, decision words, status word), so
+    two calls in flight on different streams of one device must never share a buffer.  Buffers
+    come from torch's caching allocator while their stream is current, which makes growing one
+    (dropping the old tensor) stream-ordered as well."""
+
+    def __init__(self, zero: bool, slack: float = 1.25):
+        self.zero = zero
+        self.slack = slack
+        self.bufs: dict = {}
+
+    def get(self, device, nbytes: int):
+        import torch
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self.bufs.get(key)
+        if ws is None or ws.numel() < nbytes:
+            n = int(nbytes * self.slack) + 256
+            with torch.cuda.device(device):
+                ws = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
+            self.bufs[key] = ws
+        return ws
+
+    def on_device(self, device):
+        return [ws for (d, _), ws in self.bufs.items() if d == device]

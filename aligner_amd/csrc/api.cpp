@@ -2,9 +2,12 @@
 // device probing.  Part of libaligner_amd.so (see include/aligner_amd.h).
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include <mutex>
-#include <unordered_map>
+#include <cstring>
+#include <map>
+#include <utility>
 
 #include "common.h"
 
@@ -17,16 +20,44 @@ char *error_buffer() {
 
 unsigned long long *g_debug_stamps = nullptr;
 
+// Development switches (aligner_debug_set_option): default from the environment, read once.
+static int env_flag(const char *name) { const char *e = getenv(name); return e && e[0] && e[0] != '0'; }
+int g_opt_fwdsum_one_wave = env_flag("ALIGNER_FWDSUM_ONE_WAVE");
+
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
+    // the attribute is a property of (device, kernel): a grant on one device says nothing about another
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     static std::mutex mu;
-    static std::unordered_map<const void *, size_t> granted;      // per device would be stricter; one GPU per process
+    static std::map<std::pair<int, const void *>, size_t> granted;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = granted.find(kernel);
+    const auto key = std::make_pair(dev, kernel);
+    auto it = granted.find(key);
     if (it != granted.end() && it->second >= bytes) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) granted[kernel] = bytes;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[key] = bytes;
     return e;
+}
+
+int device_lds_limit() {
+    // gfx950 lets one workgroup own the CU's whole 160 KiB LDS; cached per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 64 * 1024;
+    static std::mutex mu;
+    static std::map<int, int> limits;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = limits.find(dev);
+    if (it != limits.end()) return it->second;
+    int lim = 64 * 1024, v = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0)
+        lim = 160 * 1024;
+    else if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
+        lim = v;
+    limits[dev] = lim;
+    return lim;
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -47,6 +78,12 @@ const char *aligner_last_error(void) { return aligner::error_buffer(); }
 
 void aligner_debug_set_stamps(void *stamps_dev) {
     aligner::g_debug_stamps = static_cast<unsigned long long *>(stamps_dev);
+}
+
+int aligner_debug_set_option(const char *name, int value) {
+    if (!name) return aligner::fail(ALIGNER_EINVAL, "null option name");
+    if (std::strcmp(name, "fwdsum_one_wave") == 0) { aligner::g_opt_fwdsum_one_wave = value; return ALIGNER_OK; }
+    return aligner::fail(ALIGNER_EINVAL, "unknown option '%s'", name);
 }
 
 int aligner_device_count(void) {

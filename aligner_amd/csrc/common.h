@@ -35,10 +35,14 @@ inline int dtype_size(int dt) {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a driver call: do it once per kernel and size,
 // not on every launch (returns hipSuccess when nothing had to be done)
-hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);
+hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);   // cached per (device, kernel)
+
+// LDS bytes one workgroup may own on the current device (160 KiB on gfx950), cached per device
+int device_lds_limit();
 
 // development aid shared by the kernel files (aligner_debug_set_stamps)
 extern unsigned long long *g_debug_stamps;
+extern int g_opt_fwdsum_one_wave;      // aligner_debug_set_option("fwdsum_one_wave", ...); default: env, read once
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -698,7 +698,7 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
                    loss_out, grad_out, B, Tx, Ty, L.NT};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
-    if (!getenv("ALIGNER_FWDSUM_ONE_WAVE")) {
+    if (!g_opt_fwdsum_one_wave) {
         if (Tx <= 63 * 4) return fs_launch_sys<4, 16>(p, bwd, s);
         if (Tx <= 63 * 8) return fs_launch_sys<8, 8>(p, bwd, s);
     }

@@ -122,7 +122,7 @@ __device__ __forceinline__ int classify_lengths(const MaxpathParams &p, int b, i
         ty = 0;
         if (tx < 0) tx = 0;
     } else if (tx > ty && (p.flags & ALIGNER_F_COMPAT_TXGTTY)) {
-        mode = MODE_COMPAT;                     // reference: row t_x-1 all ones
+        mode = MODE_COMPAT;                     // reference: raw-score backtrack from row t_x-1 (write_degenerate)
     } else {
         mode = MODE_EMPTY;
         st |= ALIGNER_ST_BAD_LENGTHS;
@@ -163,20 +163,40 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
         }
 }
 
-// Outputs for the degenerate modes (whole block, uniform): no ones at all, or the
-// reference's t_x > t_y result (row t_x-1 owns every frame).
+// Outputs for the degenerate modes (whole block, uniform): no ones at all, or the reference's t_x > t_y
+// result.  For t_x > t_y the reference's forward band is empty (core.pyx:18: x_lo = t_x + y - t_y > y),
+// so `value` stays raw and its backtrack (core.pyx:32-35) walks up from row t_x-1 comparing RAW scores:
+//     index -= 1  iff  index != 0 and (index == y or value[index,y-1] < value[index-1,y-1]).
+// The comparison at y == 0 reads one float before each row (wraparound off) but happens after the last
+// path write, so the output is a function of in-bounds data only; it is reproduced here exactly (one
+// thread, t_y dependent steps: a correctness path).  The walk is monotone, so the result still has the
+// token-start form: rows the walk never reaches own no frame.
+template <int MASKMODE>
 __device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty, int *startsL) {
-    for (int x = threadIdx.x; x <= p.Tx; x += blockDim.x)
-        startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
-    __syncthreads();
-    // bisection over tx rows would name row 0; the compat answer is row tx-1 for every frame
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
-    if (p.dur)
-        for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
-    if (p.tok)
-        for (int y = tid; y < p.Ty; y += nthreads)
-            p.tok[(size_t)b * p.Ty + y] = (mode == MODE_COMPAT && y < ty) ? (tx - 1) : -1;
+    for (int x = tid; x <= p.Tx; x += nthreads) startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
+    __syncthreads();
+    if (mode == MODE_COMPAT && tid == 0) {
+        const float *val = p.value + (size_t)b * p.Tx * p.Ty;
+        const float *msk = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + (size_t)b * p.Tx * p.Ty : nullptr;
+        int index = tx - 1;
+        for (int y = ty - 1; y >= 1; --y) {
+            if (index == 0) break;
+            bool up = (index == y);
+            if (!up) {
+                float a = val[(size_t)index * p.Ty + (y - 1)], c = val[(size_t)(index - 1) * p.Ty + (y - 1)];
+                if (MASKMODE == 1) {
+                    a *= msk[(size_t)index * p.Ty + (y - 1)];
+                    c *= msk[(size_t)(index - 1) * p.Ty + (y - 1)];
+                }
+                up = a < c;
+            }
+            if (up) { startsL[index] = y; index -= 1; }        // row `index` owns frames from y on
+        }
+        // rows 0..index: `index` owns frames [0, start of index+1), the rows above it nothing
+    }
+    __syncthreads();
+    store_outputs(p, b, tx, mode == MODE_COMPAT ? ty : 0, startsL);      // no frame has a token in the empty modes
 }
 
 // --------------------------------------------------------------------------
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
 
     float *qcol = reinterpret_cast<float *>(smem);   // [2][256*R + 1], index x+1
     const int QLD = 256 * R + 1;
@@ -645,7 +665,7 @@ __global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_k
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
     ALIGNER_STAMP(0);
     ALIGNER_STAMP(6);
 
@@ -887,7 +907,7 @@ __global__ __launch_bounds__(1024) void maxpath_halo_kernel(MaxpathParams p, int
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
     ALIGNER_STAMP(0);
     ALIGNER_STAMP(6);
 
@@ -1173,22 +1193,7 @@ static WsLayout ws_layout(int B, int Tx, int Ty) {
     return L;
 }
 
-static int lds_limit() {
-    // gfx950 lets one workgroup own the CU's whole 160 KiB LDS.
-    static int lim = 0;
-    if (!lim) {
-        int dev = 0, v = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            std::strncmp(prop.gcnArchName, "gfx950", 6) == 0)
-            lim = 160 * 1024;
-        else if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0)
-            lim = v;
-        else
-            lim = 64 * 1024;
-    }
-    return lim;
-}
+static int lds_limit() { return device_lds_limit(); }
 
 static size_t starts_bytes(int Tx) { return (size_t)(((Tx + 1 + 63) / 64) * 64 + 64) * 4; }
 

@@ -25,7 +25,7 @@ _TORCH_TO_DT = {
     torch.bool: _lib.DT_U8, torch.int64: _lib.DT_I64,
 }
 
-_workspaces: dict = {}
+_workspaces = _lib.StreamWorkspaces(zero=True)     # status word: zero at allocation, sticky afterwards
 
 
 class Alignment(NamedTuple):
@@ -42,11 +42,7 @@ def _device_for(t: torch.Tensor) -> torch.device:
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
-    return ws
+    return _workspaces.get(device, nbytes)             # one per (device, stream): calls on two streams never share
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -145,15 +141,19 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
 
 
 def read_status(device=None) -> int:
-    """ALIGNER_ST_* bits left by the last align()/maximum_path() on `device` (blocking)."""
+    """ALIGNER_ST_* bits left by align()/maximum_path() calls on `device` since the last read, over all
+    streams (blocking: synchronises the device first)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    ws = _workspaces.get(device)
-    if ws is None:
-        return 0
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = 0
     out = np.zeros(1, np.int32)
     with torch.cuda.device(device):
-        _lib.check(_lib.load().aligner_maxpath_read_status(ws.data_ptr(), out.ctypes.data, _stream_ptr(device)))
-    return int(out[0])
+        torch.cuda.synchronize(device)
+        for ws in _workspaces.on_device(device):
+            _lib.check(_lib.load().aligner_maxpath_read_status(ws.data_ptr(), out.ctypes.data, _stream_ptr(device)))
+            st |= int(out[0])
+    return st
 
 
 def maximum_path(value: torch.Tensor, mask: torch.Tensor, *, mask_is_prefix: bool = False) -> torch.Tensor:

@@ -16,15 +16,11 @@ import torch
 from . import _lib
 from .softattn import _chk, _stream
 
-_fs_workspaces: dict = {}
+_fs_workspaces = _lib.StreamWorkspaces(zero=False, slack=1.0)
 
 
 def _fs_workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _fs_workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-        _fs_workspaces[device] = ws
-    return ws
+    return _fs_workspaces.get(device, nbytes)          # one per (device, stream)
 
 
 def _lengths(t: torch.Tensor, name: str, B: int, dev) -> torch.Tensor:

@@ -31,16 +31,12 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
-_workspaces: dict = {}
-_prepared: dict = {}          # (weight ptr, version, shape, device) -> (prepared weights, weight)
+_workspaces = _lib.StreamWorkspaces(zero=False)
+_prepared: dict = {}          # (weight ptr, shape, device, stream) -> (version, prepared weights, weight)
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
-        _workspaces[device] = ws
-    return ws
+    return _workspaces.get(device, nbytes)             # one per (device, stream)
 
 
 def _stream(device) -> int:
@@ -62,24 +58,34 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         # weights -> split bf16 halves in fragment order (a few microseconds), then the MFMA kernel.  The
         # prepared form is kept per weight tensor until the tensor is modified in place (torch's version
         # counter) or replaced.
-        key = (weight.data_ptr(), weight._version, Cout, Cin, K, x.device, _stream(x.device))   # (per stream: no cross-stream ordering)
-        prep = _prepared.get(key)
-        if prep is None:
+        # One entry per weight tensor (and stream: no cross-stream ordering); an in-place update bumps torch's
+        # version counter and the entry is re-prepared in place, so a training loop does not grow the cache.
+        # Updates that bypass the counter (`p.data.copy_()`, writes through a storage alias) are NOT seen:
+        # call invalidate_prepared() after such an update.
+        key = (weight.data_ptr(), Cout, Cin, K, x.device, _stream(x.device))
+        ent = _prepared.get(key)
+        if ent is None or ent[0] != weight._version:
             nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
             if nprep == 0:
                 raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
-            prep = torch.empty(nprep, dtype=torch.uint8, device=x.device)
+            prep = ent[1] if ent is not None else torch.empty(nprep, dtype=torch.uint8, device=x.device)
             _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K,
                                                       _stream(x.device)))
-            if len(_prepared) >= 64:
-                _prepared.clear()
-            _prepared[key] = (prep, weight)            # holding `weight` keeps its address from being reused
+            if ent is None and len(_prepared) >= 256:
+                _prepared.pop(next(iter(_prepared)))   # oldest entry only
+            _prepared[key] = (weight._version, prep, weight)   # holding `weight` keeps its address from being reused
         else:
-            prep = prep[0]
+            prep = ent[1]
         _lib.check(lib.aligner_conv1d_prepared_f32(x.data_ptr(), prep.data_ptr(),
                                                    None if bias is None else bias.data_ptr(), y.data_ptr(),
                                                    B, Cin, Cout, T, K, int(relu), _stream(x.device)))
     return y
+
+
+def invalidate_prepared() -> None:
+    """Drop every prepared (split-bf16) weight image: call after weight updates that bypass torch's version
+    counter (`p.data.copy_()`, EMA through `.data`, writes through a storage alias)."""
+    _prepared.clear()
 
 
 def conv1d_raw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False

@@ -55,8 +55,11 @@ extern "C" {
                                       for lengths only.  Needed only for masks
                                       that are not 0/1 prefix rectangles.      */
 #define ALIGNER_F_COMPAT_TXGTTY 2  /* t_x > t_y: reproduce the reference's
-                                      result (row t_x-1 all ones) instead of
-                                      reporting ALIGNER_ST_BAD_LENGTHS         */
+                                      result -- its forward band is empty, so
+                                      its backtrack (core.pyx:32-35) walks up
+                                      from row t_x-1 on the RAW scores --
+                                      instead of an all-zero path and
+                                      ALIGNER_ST_BAD_LENGTHS                   */
 #define ALIGNER_F_FORCE_GENERIC 4  /* use the generic (barrier-per-frame) kernel */
 #define ALIGNER_F_FORCE_HALO    8  /* use the halo-lane kernel (Tx <= 256, Ty <= 2048)
                                       instead of the 63-rows-per-wave kernel        */
@@ -133,6 +136,11 @@ int aligner_maxpath_read_status(void *workspace_dev, int32_t *status_host, void 
 /* Development aid: install (or clear with NULL) a device buffer of B*16*8 uint64 that
  * the forward kernels fill with shader-clock stamps per wave (see maxpath.hip). */
 void aligner_debug_set_stamps(void *stamps_dev);
+
+/* Development switches, process-wide: "fwdsum_one_wave" (0/1; default from the environment variable
+ * ALIGNER_FWDSUM_ONE_WAVE, read once at load) forces the one-sweeping-wave forward-sum kernels.
+ * Returns ALIGNER_EINVAL for an unknown name. */
+int aligner_debug_set_option(const char *name, int value);
 
 /*
  * Host-buffer form with exactly maximum_path_c's contract (core.pyx:40):

@@ -203,6 +203,38 @@ def wrapper_cases(refw):
     np.savez_compressed(os.path.join(HERE, "wrapper_cases.npz"), **out)
 
 
+def txgtty_cases(ref):
+    """t_x > t_y (more text than frames): undefined in spirit, but the reference's OUTPUT is a function
+    of in-bounds data only -- its forward band is empty (core.pyx:18), so the backtrack (core.pyx:32-35)
+    compares RAW scores, and the one out-of-row read (y == 0) happens after the last path write.
+    Utterance 0 of every batch is a valid one so that read stays inside the array."""
+    rng = np.random.default_rng(4242)
+    out = {}
+    n = 0
+    for (Tx, Ty) in [(4, 3), (6, 9), (12, 20), (40, 64), (70, 100), (9, 9)]:
+        for kind in range(3):
+            B = 4
+            if kind == 0:
+                v = rng.standard_normal((B, Tx, Ty))
+            elif kind == 1:
+                v = rng.integers(-1, 2, (B, Tx, Ty))           # ties
+            else:
+                v = np.zeros((B, Tx, Ty))
+            v = v.astype(np.float32)
+            ty = rng.integers(1, min(Tx - 1, Ty) + 1, B).astype(np.int32)
+            tx = np.array([rng.integers(t + 1, Tx + 1) for t in ty], np.int32)
+            tx[0], ty[0] = min(Tx, Ty), Ty                      # valid utterance in front
+            if kind == 2:
+                tx[1], ty[1] = Tx, 1                            # a single frame
+            p, q = ref_core(v, tx, ty, ref)
+            assert np.array_equal(q[1:], v[1:])                 # forward band empty: scores untouched
+            out[f"c{n}_value"], out[f"c{n}_tx"], out[f"c{n}_ty"], out[f"c{n}_path"] = v, tx, ty, p.astype(np.int8)
+            n += 1
+    out["n"] = np.int32(n)
+    np.savez_compressed(os.path.join(HERE, "kat_txgtty.npz"), **out)
+    return n
+
+
 def main():
     O.build(ref=True)
     ref = O.load_ref()
@@ -212,6 +244,7 @@ def main():
     n = small_kats(ref)
     rec = appendix_a(ref, refw)
     wrapper_cases(refw)
+    print(f"wrote {txgtty_cases(ref)} t_x > t_y cases")
     print(f"wrote {n} small KATs, {len(rec)} Appendix-A records")
     for k in ("C1-fixed", "C2-fixed", "C5-longform"):
         print(k, rec[k]["path_sha256"], rec[k]["dur0_16"])

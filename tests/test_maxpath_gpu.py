@@ -76,8 +76,8 @@ def _config(tag):
     return v, np.full(8, 500, np.int32), np.full(8, 4000, np.int32)
 
 
-@pytest.mark.parametrize("tag", ["C1-fixed", "C1-varlen", "C2-fixed", "C2-varlen", "C4-shard0", "C4-shard5",
-                                 "C5-longform"])
+@pytest.mark.parametrize("tag", ["C1-fixed", "C1-varlen", "C2-fixed", "C2-varlen"] +
+                         [f"C4-shard{s}" for s in range(8)] + ["C5-longform"])
 def test_baseline_configs_match_reference_hashes(appendix_a, dev, tag):
     """Full-size BASELINE.json configs: sha256 of the int32 path and of the durations
     equal the values captured from the real reference (tests/golden/appendix_a.json)."""
@@ -170,6 +170,47 @@ def test_long_utterances_windowed_backtrack(dev):
             _check_consistency(p, tok, dur, tx, ty)
 
 
+def test_two_streams_do_not_share_workspaces(dev):
+    """align() / soft_attention() are asynchronous on the current stream and keep live state (token starts,
+    decision words) in a workspace between their launches: calls in flight on two streams of one device must
+    not share one.  Two different batches, interleaved on two streams, each checked against the oracle."""
+    import aligner_amd
+    rng = np.random.default_rng(31)
+    shapes = [(48, 200, 1000), (64, 150, 800)]
+    vals = [rng.standard_normal(sh).astype(np.float32) for sh in shapes]
+    lens = [synth.synth_lengths(sh[0], sh[1], sh[2] // 2, sh[2], 5 + i) for i, sh in enumerate(shapes)]
+    want = [_oracle_path(v, tx, ty) for v, (tx, ty) in zip(vals, lens)]
+    dv = [torch.from_numpy(v).to(dev) for v in vals]
+    dl = [(torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)) for tx, ty in lens]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        res = [None, None]
+        for i in (0, 1) if rep % 2 == 0 else (1, 0):
+            with torch.cuda.stream(streams[i]):
+                res[i] = aligner_amd.align(dv[i], dl[i][0], dl[i][1], path_dtype=torch.int32, want_tok=True)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert np.array_equal(res[i].path.cpu().numpy(), want[i]), (rep, i)
+            assert np.array_equal(res[i].durations.cpu().numpy(), want[i].sum(2)), (rep, i)
+    # same for the similarity front end (prepared text operand in its workspace)
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(8)
+    ks = [torch.randn(16, 80, 300, generator=g), torch.randn(24, 80, 260, generator=g)]
+    qs = [torch.randn(16, 80, 900, generator=g), torch.randn(24, 80, 700, generator=g)]
+    wl = [torch.cat([S.soft_attention(k[b:b + 1], q[b:b + 1])[0] for b in range(k.shape[0])]) for k, q in zip(ks, qs)]
+    dk, dq = [k.to(dev) for k in ks], [q.to(dev) for q in qs]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        out = [None, None]
+        for i in (0, 1) if rep % 2 == 0 else (1, 0):
+            with torch.cuda.stream(streams[i]):
+                out[i] = aligner_amd.soft_attention(dk[i], dq[i])[0]
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert (out[i].cpu() - wl[i]).abs().max().item() < 1e-4, (rep, i)
+
+
 def test_wide_text_uses_generic_path(dev):
     """Tx > 512 is outside the pipelined kernel; the generic kernel must take over."""
     rng = np.random.default_rng(9)
@@ -257,13 +298,34 @@ def test_degenerate_lengths(dev):
     torch.cuda.synchronize()
     p = r.path.cpu().numpy()
     assert p[0].sum() == 0
-    assert p[1].sum() == 3 and np.all(p[1, 3, :3] == 1)         # row t_x-1 all ones
+    # t_x > t_y: the reference backtracks on the raw scores (forward band empty), see test_tx_gt_ty_*
+    assert np.array_equal(p[1], _oracle_path(v[0:2].cpu().numpy(), np.array([3, 4]), np.array([0, 3]))[1])
     assert p[2].sum() == 0
     assert aligner_amd.read_status(dev) & 1
     want = _oracle_path(v[3:].cpu().numpy(), np.array([2]), np.array([9]))
     assert np.array_equal(p[3], want[0])
     r = aligner_amd.align(v, tx, ty, path_dtype=torch.int32)
     assert r.path[1].sum().item() == 0 and (aligner_amd.read_status(dev) & 1)
+
+
+def test_tx_gt_ty_matches_reference_outputs(golden_dir, dev):
+    """More text than frames: outputs of the compiled reference (tests/golden/kat_txgtty.npz, made by
+    make_golden.py) for the compat flag the drop-in wrapper sets; with and without the strict mask."""
+    import aligner_amd
+    z = np.load(os.path.join(golden_dir, "kat_txgtty.npz"))
+    for i in range(int(z["n"])):
+        v, tx, ty, want = z[f"c{i}_value"], z[f"c{i}_tx"], z[f"c{i}_ty"], z[f"c{i}_path"].astype(np.int32)
+        for kw in ({}, {"force_generic": True}):
+            p, tok, dur = _hip(v, tx, ty, dev, compat_tx_gt_ty=True, **kw)
+            assert np.array_equal(p, want), (i, kw)
+            assert np.array_equal(dur, want.sum(2))
+            for b in range(len(tx)):
+                assert np.array_equal(tok[b, :ty[b]], want[b].argmax(0)[:ty[b]]) and np.all(tok[b, ty[b]:] == -1)
+        B, Tx, Ty = v.shape
+        mask = synth.prefix_mask(tx, ty, Tx, Ty)
+        r = aligner_amd.maximum_path(torch.from_numpy(v).to(dev), torch.from_numpy(mask).to(dev))
+        assert np.array_equal(r.cpu().numpy().astype(np.int32), want), i
+    assert aligner_amd.read_status(dev) == 0
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.int32,

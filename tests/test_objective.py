@@ -111,12 +111,14 @@ def dev():
                                              (3, 63, 150, True), (3, 127, 333, True), (2, 189, 190, False),
                                              (3, 190, 401, True), (2, 252, 640, True), (2, 253, 500, True), (2, 379, 800, True),
                                              (1, 504, 1100, False), (1, 505, 700, True)])
-def test_forward_sum_matches_oracle(dev, monkeypatch, B, Tx, Ty, ragged, one_wave):
+def test_forward_sum_matches_oracle(dev, request, B, Tx, Ty, ragged, one_wave):
     import aligner_amd
+    from aligner_amd import _lib
     if one_wave:
         if Tx > 504:
             pytest.skip("already the one-wave kernel")
-        monkeypatch.setenv("ALIGNER_FWDSUM_ONE_WAVE", "1")
+        _lib.check(_lib.load().aligner_debug_set_option(b"fwdsum_one_wave", 1))
+        request.addfinalizer(lambda: _lib.load().aligner_debug_set_option(b"fwdsum_one_wave", 0))
     rng = np.random.default_rng(B * 1000 + Tx)
     lp = _rand_logp(rng, B, Tx, Ty)
     if ragged:

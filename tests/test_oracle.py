@@ -24,6 +24,46 @@ def test_kats_path_and_q_bit_exact(kats):
             assert np.array_equal(q.view(np.uint32), c["q"].view(np.uint32)), c["tag"]
 
 
+def test_tx_gt_ty_cases_match_reference(golden_dir):
+    """More text than frames: the reference's forward band is empty, its backtrack runs on the raw scores
+    (core.pyx:18,32-35); outputs of the compiled reference in tests/golden/kat_txgtty.npz."""
+    import os
+    z = np.load(os.path.join(golden_dir, "kat_txgtty.npz"))
+    assert int(z["n"]) >= 12
+    for i in range(int(z["n"])):
+        p, q = _run(z[f"c{i}_value"], z[f"c{i}_tx"], z[f"c{i}_ty"])
+        assert np.array_equal(p, z[f"c{i}_path"].astype(np.int32)), i
+
+
+def test_restatement_under_asan_ubsan(kats):
+    """the reference switches bounds checks off (core.pyx:7-8,38-39); the CPU build of
+    its restatement runs the KATs under -fsanitize=address,undefined with every array its own exact-size
+    heap block (oracle/sanitize_driver.c).  Any out-of-bounds access or UB aborts the driver."""
+    import os
+    import struct
+    import subprocess
+    odir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-s", "-C", odir, "sanitize"])
+    blob = [struct.pack("<i", len(kats))]
+    for c in kats:
+        B, Tx, Ty = c["value"].shape
+        blob += [struct.pack("<iiif", B, Tx, Ty, c["neg"]), c["tx"].astype("<i4").tobytes(),
+                 c["ty"].astype("<i4").tobytes(), np.ascontiguousarray(c["value"], "<f4").tobytes()]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([os.path.join(odir, "sanitize_driver")], input=b"".join(blob), capture_output=True, env=env,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-2000:]
+    off = 0
+    for c in kats:
+        n = c["value"].size
+        p = np.frombuffer(r.stdout, "<i4", n, off).reshape(c["value"].shape); off += 4 * n
+        q = np.frombuffer(r.stdout, "<u4", n, off).reshape(c["value"].shape); off += 4 * n
+        assert np.array_equal(p, c["path"].astype(np.int32)), c["tag"]
+        if c["q"].size:
+            assert np.array_equal(q, c["q"].view(np.uint32)), c["tag"]
+    assert off == len(r.stdout)
+
+
 def test_inline_kats():
     # SURVEY 3.1
     v = np.arange(1, 13, dtype=np.float32).reshape(1, 3, 4)
@@ -43,7 +83,8 @@ def test_column_sweep_formulation_matches(kats):
             assert np.array_equal(got, c["path"][b].astype(np.int32)), c["tag"]
 
 
-@pytest.mark.parametrize("tag", ["C1-fixed", "C1-varlen", "C2-fixed", "C2-varlen", "C4-shard0", "C5-longform"])
+@pytest.mark.parametrize("tag", ["C1-fixed", "C1-varlen", "C2-fixed", "C2-varlen", "C4-shard0", "C4-shard3", "C4-shard7",
+                                 "C5-longform"])
 def test_appendix_a_hashes(appendix_a, tag):
     rec, _ = appendix_a
     r = rec[tag]
@@ -57,7 +98,7 @@ def test_appendix_a_hashes(appendix_a, tag):
         tx, ty = (np.full(B, Tx, np.int32), np.full(B, Ty, np.int32)) if tag == "C2-fixed" else \
             synth.synth_lengths(64, 200, 500, 1000, 2)
     elif tag.startswith("C4"):
-        v, tx, ty = synth.c4_shard(0)
+        v, tx, ty = synth.c4_shard(int(tag[-1]))
     else:
         v = synth.synth_value(*synth.CONFIGS["C5"])
         tx, ty = np.full(B, Tx, np.int32), np.full(B, Ty, np.int32)

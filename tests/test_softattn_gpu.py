@@ -66,6 +66,31 @@ def test_logp_only_path(dev, B, C, Tx, Ty):
     assert none is None and _cmp(got, want) < TOL
 
 
+def _oracle_per_utterance(k, q, t_x, **kw):
+    """The oracle evaluated one utterance at a time (its [B,C,Tx,Ty] difference tensor is 4 GB at B = 64)."""
+    from oracle import softattn_oracle as S
+    return torch.cat([S.soft_attention(k[b:b + 1], q[b:b + 1], t_x=None if t_x is None else t_x[b:b + 1], **kw)[0]
+                      for b in range(k.shape[0])])
+
+
+def test_bench_shape_matches_oracle(dev):
+    """BASELINE configs[1] at its full size [64,80,200,1000] -- the shape bench.py times, with bench.py's
+    inputs: the similarity kernel's workgroup -> (utterance, frame block) map depends on B (XCD-aware remap),
+    so the small-batch cases above do not cover it.  Full-length and ragged text."""
+    import aligner_amd
+    B, C, Tx, Ty = 64, 80, 200, 1000
+    g = torch.Generator().manual_seed(1234)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    full = torch.full((B,), Tx, dtype=torch.int32)
+    ragged = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    for t_x in (full, ragged):
+        got, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev))
+        torch.cuda.synchronize()
+        want = _oracle_per_utterance(k, q, t_x)
+        assert _cmp(got, want) < TOL
+
+
 def test_prior_and_sharp_temperature(dev):
     import aligner_amd
     from oracle import softattn_oracle as S
@@ -128,24 +153,28 @@ def test_pipeline_similarity_then_dp(dev):
     assert np.array_equal(res.path.cpu().numpy(), want)
 
 
-def test_c3_shape_full_pipeline(dev):
+@pytest.mark.parametrize("B", [6, 64])
+def test_c3_shape_full_pipeline(dev, B):
     """BASELINE config C3: conv text/mel encoders -> log-probs -> DP on an LJSpeech-shaped batch
-    (80-dim mel, ~900 frames, 512-dim text embeddings); reduced batch so the CPU oracle stays fast."""
+    (80-dim mel, ~900 frames, 512-dim text embeddings), at a small batch and at the config's B = 64
+    (oracle encoders on the whole batch, its similarity one utterance at a time)."""
     import aligner_amd
     from oracle import maxpath_oracle as O
     from oracle import softattn_oracle as S
     g = torch.Generator().manual_seed(33)
-    B, Ct, Cm, Tx, Ty = 6, 512, 80, 180, 900
+    Ct, Cm, Tx, Ty = 512, 80, 180, 900
     params = aligner_amd.AlignmentEncoderParams.random(Ct, Cm, 80, dev, seed=3)
     text = torch.randn(B, Ct, Tx, generator=g)
     mel = torch.randn(B, Cm, Ty, generator=g)
-    t_x = torch.tensor([180, 150, 121, 90, 64, 33], dtype=torch.int32)
-    t_y = torch.tensor([900, 811, 700, 512, 333, 170], dtype=torch.int32)
+    t_y = torch.randint(170, Ty + 1, (B,), generator=g, dtype=torch.int32)
+    t_x = torch.minimum(torch.randint(20, Tx + 1, (B,), generator=g, dtype=torch.int32), t_y // 4)
+    t_x[0], t_y[0] = Tx, Ty
     logp, _ = aligner_amd.alignment_encoder(text.to(dev), mel.to(dev), params, t_x=t_x.to(dev))
     res = aligner_amd.align(logp, t_x.to(dev), t_y.to(dev), path_dtype=torch.int32)
     torch.cuda.synchronize()
     cpu = lambda st: [(w.cpu(), b.cpu()) for w, b in st]  # noqa: E731
-    want_lp, _ = S.alignment_encoder(text, mel, cpu(params.key_proj), cpu(params.query_proj), t_x=t_x)
+    want_lp = _oracle_per_utterance(S.encode(text, cpu(params.key_proj)), S.encode(mel, cpu(params.query_proj)), t_x,
+                                    temperature=params.temperature)
     assert _cmp(logp, want_lp) < TOL
     v = logp.cpu().numpy().copy()
     want = np.zeros(v.shape, np.int32)
