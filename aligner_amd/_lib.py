@@ -19,7 +19,7 @@ DT_F32, DT_F16, DT_BF16, DT_F64, DT_I32, DT_U8, DT_I64 = range(7)
 F_STRICT_MASK = 1
 F_COMPAT_TXGTTY = 2
 F_FORCE_GENERIC = 4
-F_FORCE_HALO = 8
+F_NO_PREV_TABLE = 16
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2

@@ -44,6 +44,7 @@
 #include "aligner_amd.h"
 #include "common.h"
 #include "maxpath_sweep_asm.inc"
+#include "maxpath_walk_asm.inc"
 
 namespace aligner {
 
@@ -76,6 +77,7 @@ struct MaxpathParams {
     int WT;                 // tiles per backtrack window when the words live in global memory
     int bits_in_lds;        // pipelined kernel: decision words stay in LDS
     int lds_bits_off;       // byte offset of that LDS region
+    int lds_prev_off;       // byte offset of the "previous start" table P beside it (0: not kept)
     int force_exact;        // skip the v_max sweep (non-finite max_neg_val)
     float neg;
     int flags;
@@ -202,151 +204,146 @@ __device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, 
 // --------------------------------------------------------------------------
 // Backtrack over decision words (shared by both forward kernels).
 //
-// Word (tile t, row x) holds the decisions of text row x for frames 32t..32t+31,
-// frame 32t+c at bit 31-c.  Wave 0 walks rows from t_x-1 down: row x ending at
-// frame e starts at the highest set bit <= e of its own bit string (the move at
-// that frame is the reference's `index -= 1`, core.pyx:34-35).  Lane j holds the
-// row's word of tile jb+j (one coalesced LDS read per row, prefetched two rows
-// ahead); the walk state (x, e) lives in SGPRs.  Common case -- the start lies in
-// the word that contains e -- is one v_readlane plus scalar bit ops; otherwise a
-// ballot over the row's earlier words.
+// Word (tile t, row x) holds the decisions of text row x for frames 32t..32t+31, frame 32t+c at bit
+// 31-c.  Wave 0 walks rows from t_x-1 down: row x ending at frame e starts at the highest set bit <= e
+// of its own bit string (the move at that frame is the reference's `index -= 1`, core.pyx:34-35).
+// Lane j holds the row's word of window tile j; the walk state e lives in an SGPR.
 //
-// LDS overlay once the forward sweep is done: startsL at offset 0, then (words in
-// global memory only) a window of WT tiles x (ROWS+1) words.
+// The walk is a chain of t_x dependent steps on ONE wave, so its time is (cycles per step) x t_x and a
+// step is priced by what sits on the chain (tools/microbench_walk.hip, gfx950): a dependent SALU op 4.1
+// cycles, a v_readlane on the chain +27 (the VALU -> SGPR -> SALU crossing; the same off the chain: the
+// wave issues in order), s_cmp + s_cbranch +17..21 even when not taken, v_writelane 9.  The fast step
+// therefore has no branch at all (walk_row_fast):
+//     je = e >> 5;  vcc = {readlane(w, je-1) : readlane(w, je)}   the row's words of e's tile and the one before
+//     vcc >>= 31 - (e & 31)                       frame e at bit 0, frame e-k at bit k; SCC = (vcc != 0)
+//     k  = ff1(vcc)                               distance back to the row's first frame, -1 if none
+//     e' = e - k - SCC                            s_subb: (first frame) - 1 = last frame of the row above
+//     flag |= k                                   bit 31 <=> some row of the group found no bit
+//     startv[lane K] = e'
+// 67 cycles a row (the branching form it replaced: 138), and a group of 16 rows is checked once: if a row's
+// first frame lay more than a tile before e's tile (a token of 33+ frames) the group is redone from its saved
+// entry state by walk_rows_slow, which searches all the row's earlier words with a ballot.
+//
+// LDS overlay once the forward sweep is done: startsL at offset 0, then (words in global memory only) a
+// window of WT tiles x row_pitch(ROWS) words.
 // --------------------------------------------------------------------------
-// One row of the single-window backtrack with everything static: wr[K] holds row (64c+K)'s
-// words (lane = tile).  The common case (the row starts in the word that contains e) is ten
-// scalar/vector issues in one asm statement, no LDS, no loop; `ok == 0` sends the rare long
-// token to the ballot search over the row's earlier words.
-template <int K, bool CHECK>
-__device__ __forceinline__ void walk_row_static(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
-                                                int lane, int *status) {
-    const int x = xbase + K;
-    if (!CHECK || (x <= xtop && x >= 1)) {                       // uniform
-        const unsigned w = wr[K];
-        int s, ok, je, t, word;
-        asm volatile(
-            "s_lshr_b32 %[je], %[e], 5\n\t"                       // tile of frame e
-            "s_not_b32 %[t], %[e]\n\t"                            // low 5 bits: 31 - (e & 31)
-            "s_or_b32 %[s], %[e], 31\n\t"                         // last frame of that tile
-            "v_readlane_b32 %[word], %[w], %[je]\n\t"             // the row's word of that tile
-            "s_lshl_b32 %[t], -1, %[t]\n\t"                       // frames <= e  <->  bits >= 31 - (e & 31)
-            "s_and_b32 %[word], %[word], %[t]\n\t"                // SCC = some decision bit at or before e
-            "s_cselect_b32 %[ok], 1, 0\n\t"
-            "s_ff1_i32_b32 %[t], %[word]\n\t"                     // lowest set bit = latest such frame
-            "s_sub_i32 %[s], %[s], %[t]\n\t"
-            : [je] "=&s"(je), [t] "=&s"(t), [word] "=&s"(word), [s] "=&s"(s), [ok] "=&s"(ok)
-            : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [w] "v"(w)
-            : "scc");
-        if (__builtin_amdgcn_readfirstlane(ok) == 0) {
-            const unsigned long long bal = __ballot(lane < __builtin_amdgcn_readfirstlane(je) && w != 0u);
+__host__ __device__ constexpr int row_pitch(int ROWS) { return ROWS + 4; }   // 4 x odd words: the walker's 16-byte
+                                                                            // reads (lane = tile) are conflict-free
+
+// One chunk of fast steps: see maxpath_walk_asm.inc (generated by tools/gen_walk_asm.py).  `lds_addr` = this
+// lane's LDS byte address of (window tile = lane, row 64c); rows kent .. 0 of the chunk are walked.
+template <bool WINDOW>
+__device__ __forceinline__ void walk_chunk_fast(unsigned lds_addr, int kent, int &e, int &flag, int &startv, int jb,
+                                                int ntwm1) {
+    int je, jm, t, k;
+    // (no-ops on values the compiler already knows to be uniform; they keep every "s" operand provably scalar)
+    e = __builtin_amdgcn_readfirstlane(e);
+    flag = __builtin_amdgcn_readfirstlane(flag);
+    const int skip = __builtin_amdgcn_readfirstlane(63 - kent);
+    jb = __builtin_amdgcn_readfirstlane(jb);
+    ntwm1 = __builtin_amdgcn_readfirstlane(ntwm1);
+    if (WINDOW)
+        asm volatile(ALIGNER_WALK64_W
+                     : [e] "+s"(e), [flag] "+s"(flag), [sv] "+v"(startv), [je] "=&s"(je), [jm] "=&s"(jm), [t] "=&s"(t),
+                       [k] "=&s"(k)
+                     : [addr] "v"(lds_addr), [skip] "s"(skip), [jb] "s"(jb), [ntwm1] "s"(ntwm1)
+                     : ALIGNER_WALK64_CLOBBERS, "memory");
+    else
+        asm volatile(ALIGNER_WALK64
+                     : [e] "+s"(e), [flag] "+s"(flag), [sv] "+v"(startv), [je] "=&s"(je), [jm] "=&s"(jm), [t] "=&s"(t),
+                       [k] "=&s"(k)
+                     : [addr] "v"(lds_addr), [skip] "s"(skip)
+                     : ALIGNER_WALK64_CLOBBERS, "memory");
+}
+
+// The never-failing form over (W, P) tables (ALIGNER_WALK64_P): rows kent .. 0 of the chunk, no flag.
+__device__ __forceinline__ void walk_chunk_prev(unsigned lds_addr, unsigned lds_paddr, int kent, int &e, int &startv) {
+    int je, jm, t, k;
+    e = __builtin_amdgcn_readfirstlane(e);
+    const int skip = __builtin_amdgcn_readfirstlane(63 - kent);
+    asm volatile(ALIGNER_WALK64_P
+                 : [e] "+s"(e), [sv] "+v"(startv), [je] "=&s"(je), [jm] "=&s"(jm), [t] "=&s"(t), [k] "=&s"(k)
+                 : [addr] "v"(lds_addr), [paddr] "v"(lds_paddr), [skip] "s"(skip)
+                 : ALIGNER_WALK64_P_CLOBBERS, "memory");
+}
+
+// Rows xhi .. xlo (descending) with every case handled: the row's word of e's tile first, then a ballot over
+// its earlier words in the window.  `wrow` = this lane's (= window tile's) words, indexed by row.  A row whose
+// frame e lies below the window, or whose start is not in it, stops the walk: the next (earlier) window
+// resumes at row x with the same e.  Returns with (x, e) = the next row to walk and its last frame.
+__device__ __forceinline__ void walk_rows_slow(const unsigned *wrow, int xhi, int xlo, int &x, int &e, int &startv,
+                                            int lane, int jb, int ntw, int &stop, int *status, bool window) {
+    for (int xr = xhi; xr >= xlo; --xr) {
+        const unsigned w = wrow[xr];
+        const int jr = __builtin_amdgcn_readfirstlane((e >> 5) - jb);
+        int jlim = jr, en = 0;
+        bool found = false;
+        if ((unsigned)jr < (unsigned)ntw) {
+            const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)w, jr) >> ((~e) & 31);
+            if (word != 0u) { en = e - __builtin_ctz(word) - 1; found = true; }
+        } else if (jr >= ntw) {
+            jlim = ntw;                                          // e lies past this window: every word qualifies
+        }
+        if (!found && jlim > 0) {
+            const unsigned long long bal = __ballot(lane < jlim && w != 0u);
             if (bal != 0ull) {
                 const int js = 63 - __builtin_clzll(bal);
                 const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w, js);
-                s = ((js << 5) | (TC - 1)) - __builtin_ctz(wsel);
-            } else {                                             // cannot happen: the diagonal bit is always set
-                s = x;
-                if (lane == 0) atomicOr(status, ALIGNER_ST_INTERNAL);
+                en = (((jb + js) << 5) | (TC - 1)) - __builtin_ctz(wsel) - 1;
+                found = true;
             }
         }
-        s = __builtin_amdgcn_readfirstlane(s);
-        asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(startv) : "s"(s), "n"(K));   // startv[lane K] = s
-        e = __builtin_amdgcn_readfirstlane(s - 1);
+        if (!found) {
+            if (window && jb > 0) { stop = 1; x = xr; return; }  // the row continues in an earlier window
+            en = xr - 1;                                         // cannot happen: the diagonal bit is always set
+            if (lane == 0) atomicOr(status, ALIGNER_ST_INTERNAL);
+        }
+        en = __builtin_amdgcn_readfirstlane(en);
+        startv = (lane == (xr & 63)) ? en : startv;
+        e = en;
     }
+    x = xlo - 1;
 }
 
-template <int K, int KMIN, bool CHECK>
-struct WalkChunk {
-    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
-                                               int lane, int *status) {
-        walk_row_static<K, CHECK>(wr, xbase, xtop, e, startv, lane, status);
-        WalkChunk<K - 1, KMIN, CHECK>::run(wr, xbase, xtop, e, startv, lane, status);
+// One chunk of 64 rows (64c .. 64c+63), entered at row x.  Fast steps; if the flag came up, the FIRST row that
+// failed is the highest one whose step did not move e down (a failed step yields e + 1) or whose tiles were not
+// both in the window; everything above it is good.  That row takes the general search (walk_rows_slow) and the
+// fast steps are re-entered right below it.  Leaves x = the next row to walk (64c - 1, or 0 when chunk 0
+// completed: row 0 is never walked, it starts at frame 0 -- the fast steps run over it and its outcome is
+// ignored), or the row to resume at in an earlier window (stop).
+template <bool WINDOW>
+__device__ __forceinline__ void walk_chunk(const unsigned *wrow, int c, int &x, int &e, int &startv, int lane, int jb,
+                                           int ntw, int &stop, int *status) {
+    typedef __attribute__((address_space(3))) const unsigned lds_cu32;
+    const unsigned lds_addr = (unsigned)(unsigned long long)(lds_cu32 *)(wrow + 64 * c);
+    const int klo = (c == 0) ? 1 : 0;
+    int kent = x - 64 * c;
+    while (kent >= klo) {
+        const int top = kent, e_in = e;
+        int flag = 0;
+        walk_chunk_fast<WINDOW>(lds_addr, kent, e, flag, startv, jb, ntw - 1);
+        if (__builtin_expect(flag >= 0, 1)) break;
+        // e entering each row: the step result of the row above it (lane + 1), e_in for the entry row
+        int prev = __builtin_amdgcn_update_dpp(0, startv, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        prev = (lane == top) ? e_in : prev;
+        bool bad = startv >= prev;
+        if (WINDOW) bad = bad || (unsigned)((prev >> 5) - jb - 1) >= (unsigned)(ntw - 1);
+        const unsigned long long m = __ballot(bad && lane <= top && lane >= klo);
+        if (m == 0ull) break;                                    // chunk 0: only the (unwalked) row 0 raised it
+        const int kf = 63 - __builtin_clzll(m);                  // first (highest) failed row of the chunk
+        e = __builtin_amdgcn_readfirstlane((kf == top) ? e_in : __builtin_amdgcn_readlane(startv, (kf + 1) & 63));
+        x = 64 * c + kf;
+        walk_rows_slow(wrow, x, x, x, e, startv, lane, jb, ntw, stop, status, WINDOW);
+        if (stop) return;
+        kent = kf - 1;
     }
-};
-template <int KMIN, bool CHECK>
-struct WalkChunk<KMIN, KMIN, CHECK> {
-    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int xtop, int &e, int &startv,
-                                               int lane, int *status) {
-        walk_row_static<KMIN, CHECK>(wr, xbase, xtop, e, startv, lane, status);
-    }
-};
-
-// The same row step for a WINDOW of tiles [jb, jb + ntw) (decision words in the workspace, more than 64
-// tiles): lane = window-relative tile.  Rows are still static (wr[K] = row xbase+K), the window is not:
-// a row whose frame e lies below the window, or whose start is not in it, sets `stop` and the walk resumes
-// at that row in the next (earlier) window; a frame e above the window (a token that spans the boundary)
-// means every word of the window qualifies.
-template <int K>
-__device__ __forceinline__ void walk_row_window(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
-                                                int lane, int jb, int ntw, int &stop) {
-    const int xr = xbase + K;
-    if (stop == 0 && xr <= x && xr >= 1) {                       // uniform; rows above x are done already
-        const unsigned w = wr[K];
-        int s, ok, jr, jrc, valid, t, word;
-        asm volatile(
-            "s_lshr_b32 %[jr], %[e], 5\n\t"
-            "s_sub_i32 %[jr], %[jr], %[jb]\n\t"                   // window-relative tile of frame e
-            "s_not_b32 %[t], %[e]\n\t"
-            "s_or_b32 %[s], %[e], 31\n\t"                         // last frame of e's tile
-            "s_cmp_lt_u32 %[jr], %[ntw]\n\t"                      // inside the window (unsigned: also jr >= 0)
-            "s_cselect_b32 %[jrc], %[jr], 0\n\t"
-            "s_cselect_b32 %[valid], -1, 0\n\t"
-            "s_lshl_b32 %[t], -1, %[t]\n\t"                       // frames <= e  <->  bits >= 31 - (e & 31)
-            "v_readlane_b32 %[word], %[w], %[jrc]\n\t"
-            "s_and_b32 %[t], %[t], %[valid]\n\t"
-            "s_and_b32 %[word], %[word], %[t]\n\t"                // SCC = a decision bit at or before e in e's word
-            "s_cselect_b32 %[ok], 1, 0\n\t"
-            "s_ff1_i32_b32 %[t], %[word]\n\t"
-            "s_sub_i32 %[s], %[s], %[t]\n\t"
-            : [jr] "=&s"(jr), [t] "=&s"(t), [s] "=&s"(s), [jrc] "=&s"(jrc), [valid] "=&s"(valid),
-              [word] "=&s"(word), [ok] "=&s"(ok)
-            : [e] "s"(__builtin_amdgcn_readfirstlane(e)), [jb] "s"(__builtin_amdgcn_readfirstlane(jb)),
-              [ntw] "s"(__builtin_amdgcn_readfirstlane(ntw)), [w] "v"(w)
-            : "scc");
-        if (__builtin_amdgcn_readfirstlane(ok) == 0) {
-            if (jr < 0) {
-                stop = 1;                                        // row xr continues in an earlier window
-            } else {
-                if (jr > ntw) jr = ntw;                          // e lies past this window: every word qualifies
-                const unsigned long long bal = __ballot(lane < jr && w != 0u);
-                if (bal == 0ull) {
-                    stop = 1;                                    // its start lies in an earlier window
-                } else {
-                    const int js = 63 - __builtin_clzll(bal);
-                    const unsigned wsel = (unsigned)__builtin_amdgcn_readlane((int)w, js);
-                    s = (((jb + js) << 5) | (TC - 1)) - __builtin_ctz(wsel);
-                }
-            }
-        }
-        if (stop == 0) {
-            s = __builtin_amdgcn_readfirstlane(s);
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(startv) : "s"(s), "n"(K));   // row xr owns [s, e]
-            e = __builtin_amdgcn_readfirstlane(s - 1);
-            x = xr - 1;
-        }
-    }
+    x = 64 * c - 1;
+    if (c == 0) x = 0;
 }
-
-template <int K, int KMIN>
-struct WalkChunkW {
-    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
-                                               int lane, int jb, int ntw, int &stop) {
-        walk_row_window<K>(wr, xbase, x, e, startv, lane, jb, ntw, stop);
-        WalkChunkW<K - 1, KMIN>::run(wr, xbase, x, e, startv, lane, jb, ntw, stop);
-    }
-};
-template <int KMIN>
-struct WalkChunkW<KMIN, KMIN> {
-    static __device__ __forceinline__ void run(const unsigned (&wr)[64], int xbase, int &x, int &e, int &startv,
-                                               int lane, int jb, int ntw, int &stop) {
-        walk_row_window<KMIN>(wr, xbase, x, e, startv, lane, jb, ntw, stop);
-    }
-};
 
 // Decision words of `ntw` tiles, rows [0, rows_used), from the workspace into the LDS window: 16-byte loads,
 // eight in flight per thread (one element at a time this copy was a memory round trip per 4 bytes and a
-// quarter of the long-form kernel's time).  rows_used and ROWS are multiples of 64; the window's row
-// stride RP is odd (bank spread for the walk), hence the four 4-byte LDS stores.
+// quarter of the long-form kernel's time).  rows_used, ROWS and the window's row pitch are multiples of 4.
 __device__ __forceinline__ void load_window(unsigned *win, int RP, const unsigned *gbits, int ROWS, int rows_used,
                                             int ntw, int tid, int nthreads) {
     typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
@@ -365,17 +362,17 @@ __device__ __forceinline__ void load_window(unsigned *win, int RP, const unsigne
             const int idx = base + k * nthreads + tid;
             if (idx < n4) {
                 const int j = idx / q, r4 = idx - j * q;
-                unsigned *d = win + j * RP + 4 * r4;
-                d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+                *reinterpret_cast<u32x4 *>(win + j * RP + 4 * r4) = v[k];
             }
         }
     }
 }
 
+template <bool USE_PREV>
 __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthreads = blockDim.x;
-    const int RP = p.ROWS + 1;
+    const int RP = row_pitch(p.ROWS);
     int *startsL = reinterpret_cast<int *>(smem);
     const int starts_words = ((p.Tx + 1 + 63) / 64) * 64 + 64;
     unsigned *win = reinterpret_cast<unsigned *>(smem) + starts_words;
@@ -387,38 +384,14 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
     const unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS;
     const int WT = in_lds ? ntb : p.WT;
 
-    // Walk state lives in SGPRs: every update goes through readfirstlane so the loop is
-    // scalar control flow (a VGPR-carried loop costs an exec-mask dance per branch).
+    // Walk state lives in SGPRs (a VGPR-carried loop costs an exec-mask dance per branch).
     const bool walker = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;
     int x = __builtin_amdgcn_readfirstlane(tx - 1);   // core.pyx:15
     int e = __builtin_amdgcn_readfirstlane(ty - 1);
-    int startv = 0;   // starts of rows 64c..64c+63 of the chunk being walked, one per lane
+    int startv = 0;   // (first frame - 1) of rows 64c..64c+63 of the chunk being walked, one per lane
 
     const bool single = ntb <= WT;                     // every tile of the utterance in one window
-    if (single) {
-        if (!in_lds) {
-            __syncthreads();
-            load_window(win, RP, gbits, p.ROWS, rows_used, ntb, tid, nthreads);
-            __syncthreads();
-        }
-        ALIGNER_STAMP(2);
-        if (walker) {
-            const unsigned *wrow = win + (lane < ntb ? lane : 0) * RP;
-            for (int c = x >> 6; c >= 0; --c) {
-                unsigned wr[64];
-#pragma unroll
-                for (int k = 0; k < 64; ++k) wr[k] = wrow[64 * c + k];      // 64 rows x (lane = tile)
-                // the top chunk is ragged (rows above t_x-1 do not exist); chunk 0 stops at row 1
-                if (64 * c + 63 > x)  WalkChunk<63, 0, true>::run(wr, 64 * c, x, e, startv, lane, p.status);
-                else if (c == 0)      WalkChunk<63, 1, false>::run(wr, 0, x, e, startv, lane, p.status);
-                else                  WalkChunk<63, 0, false>::run(wr, 64 * c, x, e, startv, lane, p.status);
-                if (c == 0) startv = (lane == 0) ? 0 : startv;              // row 0 starts at frame 0
-                startsL[64 * c + lane] = startv;
-            }
-            x = 0;
-        }
-    }
-    for (int jhi = single ? 0 : ntb; jhi > 0; jhi -= WT) {
+    for (int jhi = ntb; jhi > 0; jhi -= WT) {
         const int jb = (jhi - WT > 0) ? (jhi - WT) : 0;
         const int ntw = jhi - jb;
         if (!in_lds) {
@@ -428,26 +401,33 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
         }
         ALIGNER_STAMP(2);
         if (walker && x >= 1) {
-            // lanes past the window read tile 0's words; they can never be selected (lane < jr <= ntw)
+            // lanes past the window read tile 0's words; they can never be selected (lane select < ntw)
             const unsigned *wrow = win + (lane < ntw ? lane : 0) * RP;
             int stop = 0;
             for (int c = x >> 6; c >= 0 && stop == 0; --c) {
-                unsigned wr[64];
-#pragma unroll
-                for (int k = 0; k < 64; ++k) wr[k] = wrow[64 * c + k];      // 64 rows x (lane = window tile)
-                WalkChunkW<63, 0>::run(wr, 64 * c, x, e, startv, lane, jb, ntw, stop);
+                if (USE_PREV && p.lds_prev_off != 0) {
+                    // decision words and the P table both in LDS (single window by construction): cannot fail
+                    typedef __attribute__((address_space(3))) const unsigned lds_cu32;
+                    const unsigned *prow = reinterpret_cast<const unsigned *>(smem + p.lds_prev_off) +
+                                           (lane < ntw ? lane : 0) * RP;
+                    walk_chunk_prev((unsigned)(unsigned long long)(lds_cu32 *)(wrow + 64 * c),
+                                    (unsigned)(unsigned long long)(lds_cu32 *)(prow + 64 * c), x - 64 * c, e, startv);
+                    x = (c == 0) ? 0 : 64 * c - 1;
+                } else if (single) {
+                    walk_chunk<false>(wrow, c, x, e, startv, lane, 0, ntw, stop, p.status);
+                } else {
+                    walk_chunk<true>(wrow, c, x, e, startv, lane, jb, ntw, stop, p.status);
+                }
                 // chunk finished (a stopped one is finished from the next window; startv carries over)
-                if (stop == 0) startsL[64 * c + lane] = startv;
+                if (stop == 0) startsL[64 * c + lane] = (c == 0 && lane == 0) ? 0 : startv + 1;
+                if (c < 4) ALIGNER_STAMP(8 + c);
             }
         }
     }
     ALIGNER_STAMP(3);
-    if (walker && !single) {
-        // x == 0 here for every valid input (forced diagonal, core.pyx:34): row 0 starts at frame 0.
-        if (x != 0 && lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
-        startv = (lane == 0) ? 0 : startv;
-        startsL[lane] = startv;
-    }
+    // x == 0 here for every valid input (forced diagonal, core.pyx:34): row 0 starts at frame 0.
+    if (walker && x != 0 && lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+    if (walker && lane == 0) startsL[0] = 0;       // (t_x == 1: nothing was walked)
     __syncthreads();
     for (int r = tx + tid; r <= p.Tx; r += nthreads) startsL[r] = ty;
     __syncthreads();
@@ -513,7 +493,7 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
     }
     __threadfence_block();
     ALIGNER_STAMP(1);
-    backtrack_and_store(p, b, tx, ty, smem);
+    backtrack_and_store<false>(p, b, tx, ty, smem);
 }
 
 // --------------------------------------------------------------------------
@@ -627,6 +607,8 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
     unsigned *gw = p.bits + (size_t)b * p.NT * p.ROWS + slot;
     float q = p.neg;
     unsigned bits = 0u;
+    int pprev = -2;
+    unsigned *prevL = reinterpret_cast<unsigned *>(smem + p.lds_prev_off);
     __syncthreads();
     if (tid == 0) qcol[0] = 0.0f;                             // core.pyx:24-25
     __syncthreads();
@@ -648,8 +630,15 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
             const int t = y / TC;
             const unsigned wv = bits << ((TC - 1) - (y & (TC - 1)));
             if (x < tx) {
-                if (p.bits_in_lds) bitsL[t * RPB + slot] = wv;
-                else               gw[(size_t)t * p.ROWS] = wv;
+                if (p.bits_in_lds) {
+                    bitsL[t * RPB + slot] = wv;
+                    if (p.lds_prev_off) {
+                        pprev = wv ? (TC * t + TC - 2 - __builtin_ctz(wv)) : pprev;
+                        prevL[t * RPB + slot] = (unsigned)pprev;
+                    }
+                } else {
+                    gw[(size_t)t * p.ROWS] = wv;
+                }
             }
             bits = 0u;
         }
@@ -658,7 +647,7 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 }
 
 template <int NW, int DEPTH, bool VEC, int MASKMODE>
-__global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_kernel(MaxpathParams p) {
+__global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -673,7 +662,7 @@ __global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_k
     float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][RING_LD]: row 63w-1 for wave w
     int   *flagp = reinterpret_cast<int *>(ring + NW * RING_T * RING_LD);   // [4] non-finite score seen
     unsigned *bitsL = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);   // [NT][ROWS+1] when in LDS
-    const int RPB = p.ROWS + 1;
+    const int RPB = row_pitch(p.ROWS);
     const int ntb = (ty + TC - 1) / TC;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
     const int nw_act = (tx + RPW - 1) / RPW;                    // waves that own at least one real row
@@ -700,6 +689,8 @@ __global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_k
             float m = 0.0f;                                     // lane 0 stays 0 through the asm sweep
             unsigned bits = 0u;
             int coll = 0;
+            int pprev = -2;                                     // P of this row so far: (last decision frame) - 1
+            unsigned *prevL = reinterpret_cast<unsigned *>(smem + p.lds_prev_off);
             const float *mytiles = tiles + w * 2 * 64 * TILE_LD + lane * TILE_LD;
             const float *myring = ring + w * RING_T * RING_LD;
             float *outring = ring + (publish ? w + 1 : w) * RING_T * RING_LD;
@@ -730,8 +721,17 @@ __global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_k
                 }
                 // unmasked stores: lanes >= 32 hit the slot's padding, the ghost lane a padding column
                 if (publish) outring[(t & (RING_T - 1)) * RING_LD + lane] = __builtin_bit_cast(float, coll);
-                if (p.bits_in_lds) bitsL[t * RPB + brow] = bits;              // frame 32t+c <-> bit 31-c
-                else               gbits[(size_t)t * p.ROWS] = bits;
+                if (p.bits_in_lds) {
+                    bitsL[t * RPB + brow] = bits;                              // frame 32t+c <-> bit 31-c
+                    if (p.lds_prev_off) {
+                        // P[t][row]: where the backtrack goes from a token of this row still running at the
+                        // end of tile t = (last frame <= 32t+31 with a decision bit) - 1  (walk_chunk_prev)
+                        pprev = bits ? (TC * t + TC - 2 - __builtin_ctz(bits)) : pprev;
+                        prevL[t * RPB + brow] = (unsigned)pprev;
+                    }
+                } else {
+                    gbits[(size_t)t * p.ROWS] = bits;
+                }
                 bits = 0u;
                 __syncthreads();
             }
@@ -831,282 +831,7 @@ __global__ __launch_bounds__(NW * 128, NW <= 4 ? 2 : 1) void maxpath_pipelined_k
     // decision words: in LDS, or in global memory written by this CU
     __threadfence_block();
     ALIGNER_STAMP(1);
-    backtrack_and_store(p, b, tx, ty, smem);
-    ALIGNER_STAMP(5);
-    ALIGNER_STAMP(7);
-}
-
-// --------------------------------------------------------------------------
-// Halo-lane forward kernel (Tx <= 256, NT <= 64, everything LDS-resident): the fast path.
-//
-// Same systolic tile pipeline as above, but a wave owns only 32 text rows (lanes 32..63) and
-// its 32 low lanes RECOMPUTE the 32 rows above it instead of receiving the boundary row through
-// LDS every frame.  A recomputed row is wrong once the missing row above the halo has propagated
-// down to it, i.e. halo lane h is wrong after frame h of a tile -- so lane 31 stays right for the
-// whole 32-frame tile, and the halo is resynchronised from the upper wave's saved registers once
-// per tile (one ds_write_b32 + one ds_read_b32 per wave and tile; nothing per frame).  The inner
-// loop is 5 VALU issues per frame for every wave (ALIGNER_HALO16_*).
-//
-// The sweep also tracks, per cell, the row its best path occupied just before the tile's first
-// frame (B, one v_cndmask_b32_dpp per frame).  At the end of a tile that is the tile's backtrack
-// transition  T_t: row at frame 32t+31 -> row at frame 32t-1,  stored as one byte per row.  The
-// backtrack then is: (1) a short serial walk through the last (partial) tile, (2) NT-2 dependent
-// table look-ups giving the path's row at every tile boundary, (3) all tiles resolved in
-// parallel, one lane per tile (each lane walks the <= 32 rows that start inside its tile).
-// --------------------------------------------------------------------------
-constexpr int HB = 32;          // real rows (and halo rows) per wave
-constexpr int HSLOTS = 3;       // LDS slots per band tile / saved-register ring
-
-struct HaloLds {                 // byte offsets inside dynamic LDS
-    int tiles, qsave, zero, flag, bits, tbl, total;
-};
-
-__host__ __device__ inline HaloLds halo_lds_layout(int nw, int NT, int ROWS) {
-    HaloLds L;
-    int o = 0;
-    L.tiles = o; o += nw * HSLOTS * HB * TILE_LD * 4;
-    L.qsave = o; o += nw * HSLOTS * 64 * 4;
-    L.zero = o;  o += TILE_LD * 4 + 16;
-    L.flag = o;  o += 16;
-    L.bits = o;  o += NT * (ROWS + 1) * 4;
-    L.tbl = o;   o += ((NT * ROWS + 15) / 16) * 16;
-    L.total = o;
-    return L;
-}
-
-template <bool DIAG>
-__device__ __forceinline__ void sweep_tile_halo(float &q, float &m, unsigned &nbits, int &B, const float4 (&vv)[8],
-                                                int rrel, float negv) {
-    float qb, cur;
-    unsigned long long sM0, sM1;
-#define ALIGNER_HALO_OPERANDS(G)                                                                         \
-    : [qa] "+v"(q), [qb] "=&v"(qb), [m] "+v"(m), [bits] "+v"(nbits), [B] "+v"(B), [cur] "=&v"(cur),      \
-      [sM0] "=&s"(sM0), [sM1] "=&s"(sM1)                                                                 \
-    : [rrel] "v"(rrel), [neg] "v"(negv),                                                                 \
-      [v0] "v"(vv[G].x), [v1] "v"(vv[G].y), [v2] "v"(vv[G].z), [v3] "v"(vv[G].w),                       \
-      [v4] "v"(vv[G + 1].x), [v5] "v"(vv[G + 1].y), [v6] "v"(vv[G + 1].z), [v7] "v"(vv[G + 1].w),       \
-      [v8] "v"(vv[G + 2].x), [v9] "v"(vv[G + 2].y), [v10] "v"(vv[G + 2].z), [v11] "v"(vv[G + 2].w),     \
-      [v12] "v"(vv[G + 3].x), [v13] "v"(vv[G + 3].y), [v14] "v"(vv[G + 3].z), [v15] "v"(vv[G + 3].w)    \
-    : "vcc"
-    if (DIAG) {
-        asm volatile(ALIGNER_HALO16_DIAG_0 ALIGNER_HALO_OPERANDS(0));
-        asm volatile(ALIGNER_HALO16_DIAG_16 ALIGNER_HALO_OPERANDS(4));
-    } else {
-        asm volatile(ALIGNER_HALO16_0 ALIGNER_HALO_OPERANDS(0));
-        asm volatile(ALIGNER_HALO16_16 ALIGNER_HALO_OPERANDS(4));
-    }
-#undef ALIGNER_HALO_OPERANDS
-}
-
-template <bool VEC, int MASKMODE>
-__global__ __launch_bounds__(1024) void maxpath_halo_kernel(MaxpathParams p, int nw) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nthreads = blockDim.x;
-    const int b = blockIdx.x;
-    int tx, ty;
-    const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
-    ALIGNER_STAMP(0);
-    ALIGNER_STAMP(6);
-
-    const HaloLds L = halo_lds_layout(nw, p.NT, p.ROWS);
-    float *tiles = reinterpret_cast<float *>(smem + L.tiles);        // [nw][HSLOTS][32][TILE_LD]
-    float *qsave = reinterpret_cast<float *>(smem + L.qsave);        // [nw][HSLOTS][64]
-    float *zrow  = reinterpret_cast<float *>(smem + L.zero);         // 36 zeros (+ wave 0's frame-0 stream)
-    int   *flagp = reinterpret_cast<int *>(smem + L.flag);
-    unsigned *bitsL = reinterpret_cast<unsigned *>(smem + L.bits);   // [NT][ROWS+1]
-    unsigned char *tbl = smem + L.tbl;                               // [NT][ROWS]
-    const int RPB = p.ROWS + 1;
-    const int ntb = (ty + TC - 1) / TC;
-    const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    const int nw_act = (tx + HB - 1) / HB;
-
-    // zrow[0..35] = 0; zrow[36..39]: {max_neg_val, 0, 0, 0} = the first piece of "row -1" in tile 0
-    for (int i = tid; i < TILE_LD + 4; i += nthreads) zrow[i] = (i == TILE_LD) ? p.neg : 0.0f;
-    if (tid == 0) flagp[0] = 0;
-    __syncthreads();
-
-    if (!p.force_exact) {
-        const int w = (wave < nw) ? wave : wave - nw;
-        const bool active = w < nw_act;
-        const int t_lo = active ? w : 0;                             // rows 32w.. start at frame 32w
-        int t_hi = active ? (ty - tx + HB * w + HB - 1) / TC : -1;
-        if (t_hi > ntb - 1) t_hi = ntb - 1;
-        const int ntiles = t_hi - t_lo + 1;
-        if (wave < nw) {
-            // ------------------------------ compute wave ------------------------------
-            const bool real = lane >= HB;
-            const int row = HB * w + lane - HB;                      // halo lanes: rows of the wave above
-            float q = p.neg;
-            float m = (w == 0) ? p.neg : 0.0f;                       // lane 0 is never written by the DPP ops
-            const float *band_lo = tiles + (w > 0 ? w - 1 : 0) * HSLOTS * HB * TILE_LD;   // halo rows' scores
-            const float *band_hi = tiles + w * HSLOTS * HB * TILE_LD;
-            const float *qs_in = qsave + (w > 0 ? w - 1 : 0) * HSLOTS * 64;
-            float *qs_out = qsave + w * HSLOTS * 64;
-
-            for (int i = 0; i < t_lo + w + 1; ++i) __syncthreads();
-            for (int t = t_lo; t <= t_hi; ++t) {
-                const int slot = t % HSLOTS;
-                // ---- resynchronise the halo lanes from the upper wave's registers after tile t-1 ----
-                if (w == 0) {
-                    if (!real) q = (t == 0 && lane == HB - 1) ? 0.0f : p.neg;      // Q[-1,-1] = 0 (core.pyx:24-27)
-                } else {
-                    const float hq = qs_in[((t + HSLOTS - 1) % HSLOTS) * 64 + (real ? lane : lane + HB)];
-                    q = real ? q : hq;
-                }
-                // ---- scores: one ds_read_b128 per 4 frames (halo lanes read the band above) ----
-                const float *base;
-                if (real) base = band_hi + (slot * HB + (lane - HB)) * TILE_LD;
-                else if (w > 0) base = band_lo + (slot * HB + lane) * TILE_LD;
-                else base = zrow;
-                const lds_f32x4 *src = (const lds_f32x4 *)base;
-                float4 vv[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const f32x4 r = src[g];
-                    vv[g] = make_float4(r.x, r.y, r.z, r.w);
-                }
-                if (w == 0 && t == 0 && lane == HB - 1) vv[0].x = p.neg;           // Q[-1,0] = max_neg_val
-                const int y0 = t * TC;
-                unsigned nbits = 0u;
-                int B = lane;
-                if (t == w) sweep_tile_halo<true>(q, m, nbits, B, vv, row - y0, p.neg);   // the diagonal's tile
-                else        sweep_tile_halo<false>(q, m, nbits, B, vv, row - y0, p.neg);
-                qs_out[slot * 64 + lane] = q;                                      // for the wave below
-                if (real) {
-                    bitsL[t * RPB + row] = ~nbits;                                 // frame 32t+c <-> bit 31-c
-                    tbl[t * p.ROWS + row] = (unsigned char)(lane - B);             // rows climbed inside tile t
-                }
-                __syncthreads();
-            }
-            for (int i = 0; i < ntb + nw - w - t_hi - 2; ++i) __syncthreads();
-        } else {
-            // ------------------------------ loader wave -------------------------------
-            if (active) {
-                const int rr = lane >> 3, cg = lane & 7;
-                float *mytiles = tiles + w * HSLOTS * HB * TILE_LD + rr * TILE_LD + 4 * cg;
-                const float *ub = p.value + ubase;
-                const float *mb = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + ubase : nullptr;
-                unsigned rowoff[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int r = HB * w + 8 * k + rr;
-                    r = r > tx - 1 ? tx - 1 : r;                    // padding rows: replay the last real row
-                    rowoff[k] = (unsigned)r * (unsigned)p.Ty;
-                }
-                unsigned nf = 0u;
-                constexpr int DEPTH = 4;
-                float4 buf[DEPTH][4];
-                auto issue = [&](float4 (&dst)[4], int t) {
-                    const int tc = t < t_hi ? t : t_hi;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        dst[k] = load_tile_piece<VEC, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
-                };
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
-                for (int i = 0; i < t_lo + w; ++i) __syncthreads();
-                for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) {
-                        const int t = t_lo + i0 + d;
-                        if (t <= t_hi) {
-                            float *dst = mytiles + (t % HSLOTS) * HB * TILE_LD;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                float4 v = buf[d][k];
-                                if (t == ntb - 1) {
-                                    const int c0 = TC * t + 4 * cg;
-                                    v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
-                                    v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
-                                }
-                                *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
-                                const unsigned a = absbits(v.x), bb = absbits(v.y), c = absbits(v.z), dd = absbits(v.w);
-                                const unsigned ab = a > bb ? a : bb, cd = c > dd ? c : dd;
-                                const unsigned mx = ab > cd ? ab : cd;
-                                nf = nf > mx ? nf : mx;
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue(buf[d], t + DEPTH);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (t <= t_hi) __syncthreads();
-                    }
-                }
-                if (nf >= 0x7F800000u) flagp[0] = 1;
-                for (int i = 0; i < ntb + nw - w - t_hi - 1; ++i) __syncthreads();
-            } else {
-                for (int i = 0; i < ntb + nw; ++i) __syncthreads();
-            }
-        }
-        __syncthreads();
-    }
-    const bool exact = p.force_exact || flagp[0] != 0;
-    if (exact) exact_fallback_sweep<MASKMODE>(p, b, tx, ty, smem, bitsL, RPB);
-    ALIGNER_STAMP(1);
-    __syncthreads();
-
-    // ------------------------------ backtrack ------------------------------
-    int *startsL = reinterpret_cast<int *>(smem);                    // overlays the (dead) score tiles
-    int *Rrow = startsL + ((p.Tx + 1 + 63) / 64) * 64 + 64;          // [NT] path row at each tile's last frame
-    if (exact) {
-        // no transition tables on this path: the generic row walk
-        MaxpathParams pe = p;
-        pe.bits_in_lds = 1;
-        pe.lds_bits_off = L.bits;
-        backtrack_and_store(pe, b, tx, ty, smem);
-        return;
-    }
-    if (wave == 0) {
-        // (1) serial walk through the last tile: rows that start at or after frame 32*(ntb-1)
-        int x = __builtin_amdgcn_readfirstlane(tx - 1);
-        int e = __builtin_amdgcn_readfirstlane(ty - 1);
-        const int tl = ntb - 1;
-        while (x >= 1) {
-            const unsigned word = bitsL[tl * RPB + x];                // uniform address: broadcast read
-            const unsigned mw = __builtin_amdgcn_readfirstlane(word & (0xFFFFFFFFu << ((~e) & (TC - 1))));
-            if (mw == 0u) break;                                     // row x started in an earlier tile
-            const int s = (e | (TC - 1)) - __builtin_ctz(mw);
-            if (lane == 0) startsL[x] = s;
-            e = s - 1;
-            x -= 1;
-            if (e < tl * TC) break;
-        }
-        // (2) the path's row at the last frame of every earlier tile: NT-2 dependent look-ups
-        int r = x;
-        if (lane == 0 && tl >= 1) Rrow[tl - 1] = r;
-        for (int t = tl - 1; t >= 1; --t) {
-            const int mv = tbl[t * p.ROWS + r];
-            r = __builtin_amdgcn_readfirstlane(r - mv);
-            r = r < 0 ? 0 : r;
-            if (lane == 0) Rrow[t - 1] = r;
-        }
-    }
-    __syncthreads();
-    if (wave == 0 && lane < ntb - 1) {
-        // (3) lane = tile: rows (R[t-1], R[t]] start inside tile t; highest set bit at or below `lim`
-        const int t = lane;
-        int xr = Rrow[t];
-        const int xstop = (t >= 1) ? Rrow[t - 1] : 0;
-        int lim = TC - 1;
-        while (xr > xstop) {
-            const unsigned wd = bitsL[t * RPB + xr] & (0xFFFFFFFFu << (TC - 1 - lim));
-            if (wd == 0u) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }   // cannot happen
-            const int c = (TC - 1) - __builtin_ctz(wd);
-            startsL[xr] = t * TC + c;
-            lim = c - 1;
-            xr -= 1;
-            if (lim < 0 && xr > xstop) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
-        }
-    }
-    if (tid == 0) startsL[0] = 0;                                    // row 0 starts at frame 0
-    __syncthreads();
-    for (int r2 = tx + tid; r2 <= p.Tx; r2 += nthreads) startsL[r2] = ty;
-    __syncthreads();
-    ALIGNER_STAMP(3);
-    store_outputs(p, b, tx, ty, startsL);
+    backtrack_and_store<(NW <= 4)>(p, b, tx, ty, smem);
     ALIGNER_STAMP(5);
     ALIGNER_STAMP(7);
 }
@@ -1198,7 +923,7 @@ static int lds_limit() { return device_lds_limit(); }
 static size_t starts_bytes(int Tx) { return (size_t)(((Tx + 1 + 63) / 64) * 64 + 64) * 4; }
 
 // Backtrack overlay size for a window of WT tiles (decision words in global memory).
-static size_t walk_bytes(int WT, int ROWS, int Tx) { return starts_bytes(Tx) + (size_t)WT * (ROWS + 1) * 4; }
+static size_t walk_bytes(int WT, int ROWS, int Tx) { return starts_bytes(Tx) + (size_t)WT * row_pitch(ROWS) * 4; }
 
 static int pick_window(int NT, int ROWS, int Tx, size_t budget) {
     int WT = NT < 64 ? NT : 64;
@@ -1268,7 +993,7 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     p.status = reinterpret_cast<int *>(wsb + L.status_off);
     p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
     p.neg = neg; p.flags = flags;
-    p.bits_in_lds = 0; p.lds_bits_off = 0;
+    p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0;
     p.force_exact = !(neg - neg == 0.0f);            // NaN / inf max_neg_val
     p.stamps = g_debug_stamps;
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
@@ -1278,44 +1003,24 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
                      (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
                      (size_t)Tx * (size_t)Ty * 4 < (1ull << 31);
 
-    // halo-lane kernel (opt-in: measured on par with the 63-rows-per-wave kernel at [64,200,1000] --
-    // 5 instead of 6 issues per frame and a 3x faster table-driven backtrack, but 7 instead of 4
-    // compute waves share the CU's SIMDs and LDS)
-    if ((flags & ALIGNER_F_FORCE_HALO) && !(flags & ALIGNER_F_FORCE_GENERIC) && Tx <= 8 * HB && L.NT <= 64) {
-        const int nwh = (Tx + HB - 1) / HB;
-        const HaloLds HL = halo_lds_layout(nwh, L.NT, L.ROWS);
-        const size_t fb = (size_t)2 * (2 * nwh * 64 + 1) * 4;            // exact fallback's column buffers
-        if ((size_t)HL.total <= lds_max && starts_bytes(Tx) + (size_t)L.NT * 4 <= (size_t)HL.bits &&
-            fb <= (size_t)HL.bits) {
-            p.WT = L.NT;
-            p.bits_in_lds = 1;
-            p.lds_bits_off = HL.bits;
-            dim3 grid(B), block(2 * nwh * 64);
-            auto launch = [&](auto kern) {
-                hipError_t e_ = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), (size_t)HL.total);
-                if (e_ != hipSuccess) return fail(ALIGNER_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e_));
-                hipLaunchKernelGGL(kern, grid, block, (size_t)HL.total, s, p, nwh);
-                hipError_t e2 = hipGetLastError();
-                if (e2 != hipSuccess) return fail(ALIGNER_EHIP, "launch failed: %s", hipGetErrorString(e2));
-                return (int)ALIGNER_OK;
-            };
-            if (vec) return maskmode ? launch(maxpath_halo_kernel<true, 1>) : launch(maxpath_halo_kernel<true, 0>);
-            return maskmode ? launch(maxpath_halo_kernel<false, 1>) : launch(maxpath_halo_kernel<false, 0>);
-        }
-    }
-
     const int nw_need = (Tx + RPW - 1) / RPW;
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8) {
         const int NW = nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
         const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * RING_LD) * 4 + 16, 16);
         if (fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = 0;
-            const size_t bits_lds = (size_t)L.NT * (L.ROWS + 1) * 4;
+            const size_t bits_lds = (size_t)L.NT * row_pitch(L.ROWS) * 4;
             if (L.NT <= 64 && fwd + bits_lds <= lds_max) {
                 p.bits_in_lds = 1;
                 p.lds_bits_off = (int)fwd;
                 p.WT = L.NT;
                 lds = fwd + bits_lds;
+                // room for the P table as well (and a walk with (W, P) in 128 + 64 VGPRs: NW <= 4): the
+                // backtrack's steps then cannot fail (walk_chunk_prev)
+                if (NW <= 4 && lds + bits_lds <= lds_max && !(flags & ALIGNER_F_NO_PREV_TABLE)) {
+                    p.lds_prev_off = (int)lds;
+                    lds += bits_lds;
+                }
             } else {
                 p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
                 if (p.WT > 0) {

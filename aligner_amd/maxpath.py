@@ -58,7 +58,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           want_path: bool = True, path_dtype: Optional[torch.dtype] = None,
           want_tok: bool = False, want_durations: bool = True,
           max_neg_val: float = -1e9, compat_tx_gt_ty: bool = False,
-          force_generic: bool = False, force_halo: bool = False,
+          force_generic: bool = False, no_prev_table: bool = False,
           out_path: Optional[torch.Tensor] = None) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
@@ -127,7 +127,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
             flags = (_lib.F_STRICT_MASK if strict_mask else 0) | \
                     (_lib.F_COMPAT_TXGTTY if compat_tx_gt_ty else 0) | \
                     (_lib.F_FORCE_GENERIC if force_generic else 0) | \
-                    (_lib.F_FORCE_HALO if force_halo else 0)
+                    (_lib.F_NO_PREV_TABLE if no_prev_table else 0)
             _lib.check(lib.aligner_maxpath_f32(
                 v.data_ptr(), _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
                 ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))

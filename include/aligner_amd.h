@@ -61,8 +61,9 @@ extern "C" {
                                       instead of an all-zero path and
                                       ALIGNER_ST_BAD_LENGTHS                   */
 #define ALIGNER_F_FORCE_GENERIC 4  /* use the generic (barrier-per-frame) kernel */
-#define ALIGNER_F_FORCE_HALO    8  /* use the halo-lane kernel (Tx <= 256, Ty <= 2048)
-                                      instead of the 63-rows-per-wave kernel        */
+
+#define ALIGNER_F_NO_PREV_TABLE 16 /* testing: do not keep the backtrack's second LDS table (the walk then
+                                      takes the flag-and-retry steps it uses for long utterances)   */
 
 /* bits of the device status word (aligner_maxpath_read_status) */
 #define ALIGNER_ST_BAD_LENGTHS  1  /* some utterance had t_x < 1 or t_x > t_y

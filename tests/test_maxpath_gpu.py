@@ -45,12 +45,12 @@ def _check_consistency(path, tok, dur, tx, ty):
             assert np.array_equal(path[b].argmax(0)[:ty[b]], tok[b, :ty[b]])
 
 
-KERNELS = {"wide": {}, "halo": {"force_halo": True}, "generic": {"force_generic": True}}
+KERNELS = {"wide": {}, "wide_retry_walk": {"no_prev_table": True}, "generic": {"force_generic": True}}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
 def test_kats_bit_exact(kats, dev, kernel):
-    """All three forward kernels (63-rows-per-wave pipelined, halo-lane, generic)."""
+    """Both forward kernels (63-rows-per-wave pipelined -- with either form of the backtrack walk --, generic)."""
     import aligner_amd
     for c in kats:
         p, tok, dur = _hip(c["value"], c["tx"], c["ty"], dev, max_neg_val=c["neg"], **KERNELS[kernel])
@@ -89,7 +89,7 @@ def test_baseline_configs_match_reference_hashes(appendix_a, dev, tag):
     _check_consistency(p, tok, dur, tx, ty)
 
 
-@pytest.mark.parametrize("kernel", ["halo", "generic"])
+@pytest.mark.parametrize("kernel", ["wide_retry_walk", "generic"])
 def test_other_kernels_agree_on_c2(appendix_a, dev, kernel):
     rec, _ = appendix_a
     for tag in ("C2-fixed", "C2-varlen"):

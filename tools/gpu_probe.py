@@ -40,12 +40,12 @@ def main():
     # --- correctness on golden KATs, both kernels ---
     z = np.load(os.path.join(ROOT, "tests", "golden", "kat_small.npz"))
     n = int(z["n"])
-    for generic in (False, True, "halo"):
+    for generic in (False, True):
         bad = []
         for i in range(n):
             v, tx, ty = z[f"c{i}_value"], z[f"c{i}_tx"], z[f"c{i}_ty"]
             r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
-                                  path_dtype=torch.int32, max_neg_val=float(z[f"c{i}_neg"]), force_generic=(generic is True), force_halo=(generic == "halo"))
+                                  path_dtype=torch.int32, max_neg_val=float(z[f"c{i}_neg"]), force_generic=(generic is True))
             torch.cuda.synchronize()
             if not np.array_equal(r.path.cpu().numpy(), z[f"c{i}_path"].astype(np.int32)):
                 bad.append(str(z["tags"][i]))

@@ -57,7 +57,7 @@ def main():
         want = oracle(v, tx, ty, neg)
         vd = torch.from_numpy(v).to(dev)
         txd, tyd = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
-        for name, kw in (("auto", {}), ("generic", {"force_generic": True}), ("halo", {"force_halo": True})):
+        for name, kw in (("auto", {}), ("generic", {"force_generic": True})):
             if name == "generic" and it % 4:
                 continue
             got = aligner_amd.align(vd, txd, tyd, path_dtype=torch.int32, max_neg_val=neg, **kw).path.cpu().numpy()
