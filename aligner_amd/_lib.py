@@ -40,6 +40,10 @@ SIGNATURES = {
     "aligner_lengths_from_mask": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "aligner_maxpath_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,
                                  _i, _i, _i, _f, _i, _vp]),
+    "aligner_maxpath": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,
+                             _i, _i, _i, _f, _i, _vp]),
+    "aligner_maxpath_forward": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
+                                     _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_forward_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                          _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -64,7 +64,7 @@ typedef float __attribute__((ext_vector_type(4))) f32x4;
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4;    // 16-byte aligned: ds_read_b128
 
 struct MaxpathParams {
-    const float *value;
+    const void  *value;     // scores [B,Tx,Ty]: fp32, or bf16 / fp16 (template VT) up-cast on the fly
     const void  *mask;      // strict-mask operand (nullable)
     const int   *t_xs;
     const int   *t_ys;
@@ -97,6 +97,26 @@ struct MaxpathParams {
 // --------------------------------------------------------------------------
 // small device helpers
 // --------------------------------------------------------------------------
+// Score element types (template VT).  The reference computes in fp32 whatever the input dtype
+// (__init__.py:14 astype(np.float32)); 16-bit scores are up-cast exactly, in the loaders.
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F16 = 2 };
+
+template <int VT> __device__ __forceinline__ float half_to_f32(unsigned h16) {          // h16: the 16 bits, zero-extended
+    if (VT == VT_BF16) return __builtin_bit_cast(float, h16 << 16);
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)h16);
+}
+// value * mask as torch evaluates it for two tensors of this dtype (__init__.py:11): fp32 product, rounded to
+// nearest-even in the tensors' dtype; then the fp32 up-cast of __init__.py:14
+template <int VT> __device__ __forceinline__ float mul_in_dtype(float v, float m) {
+    const float r = v * m;
+    if (VT == VT_BF16) return (float)(__bf16)r;
+    if (VT == VT_F16) return (float)(_Float16)r;
+    return r;
+}
+template <int VT> __device__ __forceinline__ float load_score(const void *base, size_t idx) {
+    if (VT == VT_F32) return static_cast<const float *>(base)[idx];
+    return half_to_f32<VT>(static_cast<const unsigned short *>(base)[idx]);
+}
 __device__ __forceinline__ float dpp_wave_shr1(float old_lane0, float src) {
     // lane i <- src[lane i-1]; lane 0 keeps `old_lane0` (bound_ctrl off).
     return __builtin_bit_cast(
@@ -173,23 +193,23 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
 // path write, so the output is a function of in-bounds data only; it is reproduced here exactly (one
 // thread, t_y dependent steps: a correctness path).  The walk is monotone, so the result still has the
 // token-start form: rows the walk never reaches own no frame.
-template <int MASKMODE>
+template <int MASKMODE, int VT>
 __device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, int mode, int tx, int ty, int *startsL) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     for (int x = tid; x <= p.Tx; x += nthreads) startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
     __syncthreads();
     if (mode == MODE_COMPAT && tid == 0) {
-        const float *val = p.value + (size_t)b * p.Tx * p.Ty;
-        const float *msk = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + (size_t)b * p.Tx * p.Ty : nullptr;
+        const size_t ub = (size_t)b * p.Tx * p.Ty;
         int index = tx - 1;
         for (int y = ty - 1; y >= 1; --y) {
             if (index == 0) break;
             bool up = (index == y);
             if (!up) {
-                float a = val[(size_t)index * p.Ty + (y - 1)], c = val[(size_t)(index - 1) * p.Ty + (y - 1)];
+                const size_t ia = ub + (size_t)index * p.Ty + (y - 1), ic = ub + (size_t)(index - 1) * p.Ty + (y - 1);
+                float a = load_score<VT>(p.value, ia), c = load_score<VT>(p.value, ic);
                 if (MASKMODE == 1) {
-                    a *= msk[(size_t)index * p.Ty + (y - 1)];
-                    c *= msk[(size_t)(index - 1) * p.Ty + (y - 1)];
+                    a = mul_in_dtype<VT>(a, load_score<VT>(p.mask, ia));
+                    c = mul_in_dtype<VT>(c, load_score<VT>(p.mask, ic));
                 }
                 up = a < c;
             }
@@ -420,7 +440,6 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
                 }
                 // chunk finished (a stopped one is finished from the next window; startv carries over)
                 if (stop == 0) startsL[64 * c + lane] = (c == 0 && lane == 0) ? 0 : startv + 1;
-                if (c < 4) ALIGNER_STAMP(8 + c);
             }
         }
     }
@@ -438,18 +457,18 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
 // Generic forward kernel: any Tx <= 256*R, one barrier per frame.  Slow but
 // shape-agnostic; also the independent cross-check of the pipelined kernel.
 // --------------------------------------------------------------------------
-template <int R, int MASKMODE>
+template <int R, int MASKMODE, int VT>
 __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE, VT>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
 
     float *qcol = reinterpret_cast<float *>(smem);   // [2][256*R + 1], index x+1
     const int QLD = 256 * R + 1;
-    const float *val = p.value + (size_t)b * p.Tx * p.Ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
     unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS;
 
     float q[R];
@@ -469,9 +488,8 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
                 const float up = src[x];                           // Q[x-1,y-1] (or the x==0 edge)
                 const float cur = (x == y) ? p.neg : q[r];         // core.pyx:19-22
                 const bool adv = up > cur;                         // core.c:19384
-                float v = val[(size_t)x * p.Ty + y];
-                if (MASKMODE == 1)
-                    v = v * reinterpret_cast<const float *>(p.mask)[((size_t)b * p.Tx + x) * p.Ty + y];
+                float v = load_score<VT>(p.value, ubase + (size_t)x * p.Ty + y);
+                if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.Ty + y));
                 q[r] = (adv ? up : cur) + v;                       // core.pyx:30
                 // backtrack predicate (core.pyx:34): the diagonal move is forced whatever the scores
                 bits[r] = (bits[r] << 1) | ((adv || x == y) ? 1u : 0u);
@@ -540,8 +558,8 @@ __device__ __forceinline__ void scan4(float &nf, const float4 &v) {
 // changes (row and column group) plus a scalar tile offset, so a tile costs the loader no address
 // arithmetic; reads past the block (last rows, last partial tile) return 0 instead of faulting.
 typedef unsigned __attribute__((ext_vector_type(4))) u32x4r;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t utterance_rsrc(const float *base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, bytes, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t utterance_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     // (cast the whole vector: hipcc 7.2 turns per-component reads of the builtin's result into a
@@ -595,13 +613,13 @@ __device__ __forceinline__ void sweep_tile_fast(float &q, float &m, unsigned &bi
 // workgroup: one text row per thread, one barrier per frame, decision words written in
 // the same (tile, row) layout so the shared backtrack reads them unchanged.  Only taken for
 // utterances whose scores contain a NaN/infinity -- correctness path, not a fast path.
-template <int MASKMODE>
+template <int MASKMODE, int VT>
 __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int b, int tx, int ty, unsigned char *smem,
                                                    unsigned *bitsL, int RPB) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     float *qcol = reinterpret_cast<float *>(smem);            // [2][nthreads + 1], index x+1
     const int QLD = nthreads + 1;
-    const float *val = p.value + (size_t)b * p.Tx * p.Ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
     const int x = tid;                                        // tx <= 63*NW < nthreads
     const int slot = x;
     unsigned *gw = p.bits + (size_t)b * p.NT * p.ROWS + slot;
@@ -619,8 +637,8 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
             const float up = src[x];
             const float cur = (x == y) ? p.neg : q;             // core.pyx:19-22
             const bool adv = up > cur;                          // core.c:19384
-            float v = val[(size_t)x * p.Ty + y];
-            if (MASKMODE == 1) v *= reinterpret_cast<const float *>(p.mask)[((size_t)b * p.Tx + x) * p.Ty + y];
+            float v = load_score<VT>(p.value, ubase + (size_t)x * p.Ty + y);
+            if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.Ty + y));
             q = (adv ? up : cur) + v;                           // core.pyx:30
             bits = (bits << 1) | ((adv || x == y) ? 1u : 0u);   // core.pyx:34
             dst[x + 1] = q;
@@ -646,7 +664,7 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
     }
 }
 
-template <int NW, int DEPTH, bool VEC, int MASKMODE>
+template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT>
 __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,7 +672,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     const int b = blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE, VT>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
     ALIGNER_STAMP(0);
     ALIGNER_STAMP(6);
 
@@ -739,82 +757,156 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         } else {
             // ------------------------------ loader wave -------------------------------
             if (active) {
-                const int rr = lane >> 3, cg = lane & 7;
-                float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 4 * cg;
-                const float *ub = p.value + ubase;
-                const float *mb = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + ubase : nullptr;
-                // LDS row slot 8k+rr <-> text row 63w + 8k + rr - 1 (slot 0 is the ghost lane's: never read)
-                unsigned rowoff[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    // rows past the utterance's own text (padding: often -inf log-probs) are replaced
-                    // by its last row: they are never read by the DP and must not trip the finiteness scan
-                    int r = RPW * w + 8 * k + rr - 1;
-                    r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
-                    rowoff[k] = (unsigned)r * (unsigned)p.Ty;
-                }
                 float nf = 0.f;                             // maximum |score| seen, NaN-propagating (scan4)
-                float4 buf[DEPTH][8];
-                // VEC: buffer loads, per-lane byte offsets fixed for the whole sweep + a scalar tile offset
-                const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 4u;
-                const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
-                const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(MASKMODE == 1 ? mb : ub, ubytes);
-                unsigned voff[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) voff[k] = (rowoff[k] + 4u * (unsigned)cg) * 4u;
-                // every refill is issued unconditionally (tile index clamped to t_hi: duplicates hit
-                // L2) so the number of loads in flight at each register->LDS pass is a constant
-                auto issue = [&](float4 (&dst)[8], int t) {
-                    const int tc = t < t_hi ? t : t_hi;
-                    if (VEC) {
-                        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(TC * tc * 4);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            dst[k] = buffer_load4(urs, voff[k], soff);
-                            if (MASKMODE == 1) {
-                                const float4 mk = buffer_load4(mrs, voff[k], soff);
-                                dst[k].x *= mk.x; dst[k].y *= mk.y; dst[k].z *= mk.z; dst[k].w *= mk.w;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            dst[k] = load_tile_piece<false, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
+                if (VT == VT_F32) {
+                    const int rr = lane >> 3, cg = lane & 7;
+                    float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 4 * cg;
+                    const float *ub = static_cast<const float *>(p.value) + ubase;
+                    const float *mb = (MASKMODE == 1) ? reinterpret_cast<const float *>(p.mask) + ubase : nullptr;
+                    // LDS row slot 8k+rr <-> text row 63w + 8k + rr - 1 (slot 0 is the ghost lane's: never read)
+                    unsigned rowoff[8];
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        // rows past the utterance's own text (padding: often -inf log-probs) are replaced
+                        // by its last row: they are never read by the DP and must not trip the finiteness scan
+                        int r = RPW * w + 8 * k + rr - 1;
+                        r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
+                        rowoff[k] = (unsigned)r * (unsigned)p.Ty;
                     }
-                };
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
-                for (int i = 0; i < t_lo + w; ++i) __syncthreads();
-                for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
-#pragma unroll
-                    for (int d = 0; d < DEPTH; ++d) {
-                        const int t = t_lo + i0 + d;
-                        if (t <= t_hi) {
-                            float *dst = mytiles + (t & 1) * 64 * TILE_LD;
-                            if (t == ntb - 1) {
-                                // frames >= t_y (mel padding, or past the row's end) never matter: zero them
-                                const int c0 = TC * t + 4 * cg;
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    float4 v = buf[d][k];
-                                    v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
-                                    v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
-                                    *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
-                                    scan4(nf, v);
-                                }
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < 8; ++k) {
-                                    const float4 v = buf[d][k];
-                                    *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
-                                    scan4(nf, v);
+                    float4 buf[DEPTH][8];
+                    // VEC: buffer loads, per-lane byte offsets fixed for the whole sweep + a scalar tile offset
+                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 4u;
+                    const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
+                    const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(MASKMODE == 1 ? mb : ub, ubytes);
+                    unsigned voff[8];
+    #pragma unroll
+                    for (int k = 0; k < 8; ++k) voff[k] = (rowoff[k] + 4u * (unsigned)cg) * 4u;
+                    // every refill is issued unconditionally (tile index clamped to t_hi: duplicates hit
+                    // L2) so the number of loads in flight at each register->LDS pass is a constant
+                    auto issue = [&](float4 (&dst)[8], int t) {
+                        const int tc = t < t_hi ? t : t_hi;
+                        if (VEC) {
+                            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(TC * tc * 4);
+    #pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                dst[k] = buffer_load4(urs, voff[k], soff);
+                                if (MASKMODE == 1) {
+                                    const float4 mk = buffer_load4(mrs, voff[k], soff);
+                                    dst[k].x *= mk.x; dst[k].y *= mk.y; dst[k].z *= mk.z; dst[k].w *= mk.w;
                                 }
                             }
+                        } else {
+    #pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                dst[k] = load_tile_piece<false, MASKMODE>(ub, mb, rowoff[k], TC * tc + 4 * cg, p.Ty);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue(buf[d], t + DEPTH);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (t <= t_hi) __syncthreads();
+                    };
+    #pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
+                    for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                    for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+    #pragma unroll
+                        for (int d = 0; d < DEPTH; ++d) {
+                            const int t = t_lo + i0 + d;
+                            if (t <= t_hi) {
+                                float *dst = mytiles + (t & 1) * 64 * TILE_LD;
+                                if (t == ntb - 1) {
+                                    // frames >= t_y (mel padding, or past the row's end) never matter: zero them
+                                    const int c0 = TC * t + 4 * cg;
+    #pragma unroll
+                                    for (int k = 0; k < 8; ++k) {
+                                        float4 v = buf[d][k];
+                                        v.x = (c0 + 0 < ty) ? v.x : 0.f; v.y = (c0 + 1 < ty) ? v.y : 0.f;
+                                        v.z = (c0 + 2 < ty) ? v.z : 0.f; v.w = (c0 + 3 < ty) ? v.w : 0.f;
+                                        *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                        scan4(nf, v);
+                                    }
+                                } else {
+    #pragma unroll
+                                    for (int k = 0; k < 8; ++k) {
+                                        const float4 v = buf[d][k];
+                                        *reinterpret_cast<float4 *>(dst + 8 * k * TILE_LD) = v;
+                                        scan4(nf, v);
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(buf[d], t + DEPTH);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (t <= t_hi) __syncthreads();
+                        }
+                    }
+                } else {
+                    // 16-bit scores (bf16 / fp16): 16 bytes = 8 frames, so one instruction covers 16 rows x 32 frames
+                    // and a tile is 4 loads; the up-cast to fp32 (exact) happens on the way into LDS, where the
+                    // compute waves find the same padded fp32 tile as for fp32 scores.
+                    const int rr = lane >> 2, cg = lane & 3;
+                    float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 8 * cg;
+                    const unsigned short *ub = static_cast<const unsigned short *>(p.value) + ubase;
+                    const unsigned short *mb = (MASKMODE == 1) ? static_cast<const unsigned short *>(p.mask) + ubase : ub;
+                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 2u;
+                    const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
+                    const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(mb, ubytes);
+                    unsigned voff[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // LDS row slot 16k+rr <-> text row 63w + 16k + rr - 1; rows outside the utterance's own text
+                        // are replaced by its last row (never read by the DP, must not trip the finiteness scan)
+                        int r = RPW * w + 16 * k + rr - 1;
+                        r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
+                        voff[k] = ((unsigned)r * (unsigned)p.Ty + 8u * (unsigned)cg) * 2u;
+                    }
+                    u32x4r buf[DEPTH][4], mbuf[MASKMODE == 1 ? DEPTH : 1][4];
+                    auto issue = [&](int d, int t) {
+                        const int tc = t < t_hi ? t : t_hi;
+                        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(TC * tc * 2);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            buf[d][k] = __builtin_amdgcn_raw_buffer_load_b128(urs, voff[k], soff, 0);
+                            if (MASKMODE == 1) mbuf[d][k] = __builtin_amdgcn_raw_buffer_load_b128(mrs, voff[k], soff, 0);
+                        }
+                    };
+#pragma unroll
+                    for (int d = 0; d < DEPTH; ++d) issue(d, t_lo + d);
+                    for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                    for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+#pragma unroll
+                        for (int d = 0; d < DEPTH; ++d) {
+                            const int t = t_lo + i0 + d;
+                            if (t <= t_hi) {
+                                float *dst = mytiles + (t & 1) * 64 * TILE_LD;
+                                const int c0 = TC * t + 8 * cg;
+                                const bool tail = (t == ntb - 1);   // frames >= t_y never matter: zero them
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) {
+                                    float f[8];
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        const unsigned u = buf[d][k][i];
+                                        f[2 * i] = half_to_f32<VT>(u & 0xFFFFu);
+                                        f[2 * i + 1] = half_to_f32<VT>(u >> 16);
+                                        if (MASKMODE == 1) {
+                                            const unsigned mu = mbuf[MASKMODE == 1 ? d : 0][k][i];
+                                            f[2 * i] = mul_in_dtype<VT>(f[2 * i], half_to_f32<VT>(mu & 0xFFFFu));
+                                            f[2 * i + 1] = mul_in_dtype<VT>(f[2 * i + 1], half_to_f32<VT>(mu >> 16));
+                                        }
+                                    }
+                                    if (tail) {
+#pragma unroll
+                                        for (int i = 0; i < 8; ++i) f[i] = (c0 + i < ty) ? f[i] : 0.f;
+                                    }
+                                    const float4 v0 = make_float4(f[0], f[1], f[2], f[3]), v1 = make_float4(f[4], f[5], f[6], f[7]);
+                                    *reinterpret_cast<float4 *>(dst + 16 * k * TILE_LD) = v0;
+                                    *reinterpret_cast<float4 *>(dst + 16 * k * TILE_LD + 4) = v1;
+                                    scan4(nf, v0);
+                                    scan4(nf, v1);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            issue(d, t + DEPTH);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (t <= t_hi) __syncthreads();
+                        }
                     }
                 }
                 if (absbits(nf) >= 0x7F800000u) flagp[0] = 1;   // benign race: every writer stores 1
@@ -827,7 +919,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
     // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
-    if (p.force_exact || flagp[0] != 0) exact_fallback_sweep<MASKMODE>(p, b, tx, ty, smem, bitsL, RPB);
+    if (p.force_exact || flagp[0] != 0) exact_fallback_sweep<MASKMODE, VT>(p, b, tx, ty, smem, bitsL, RPB);
     // decision words: in LDS, or in global memory written by this CU
     __threadfence_block();
     ALIGNER_STAMP(1);
@@ -871,15 +963,20 @@ __global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ sta
 // --------------------------------------------------------------------------
 // lengths from the mask (__init__.py:18-19)
 // --------------------------------------------------------------------------
-template <typename T>
+template <typename T, int VT> __device__ __forceinline__ float mask_value(T v) {
+    if (VT == VT_F32) return (float)v;
+    return half_to_f32<VT>((unsigned)v);                          // T = unsigned short holding bf16 / fp16 bits
+}
+
+template <typename T, int VT = VT_F32>
 __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask, int Tx, int Ty,
                                                        int *__restrict__ t_xs, int *__restrict__ t_ys) {
     __shared__ float red[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const T *m = mask + (size_t)b * Tx * Ty;
     float sx = 0.f, sy = 0.f;
-    for (int x = tid; x < Tx; x += 256) sx += (float)m[(size_t)x * Ty];   // mask[b, x, 0]
-    for (int y = tid; y < Ty; y += 256) sy += (float)m[y];                // mask[b, 0, y]
+    for (int x = tid; x < Tx; x += 256) sx += mask_value<T, VT>(m[(size_t)x * Ty]);   // mask[b, x, 0]
+    for (int y = tid; y < Ty; y += 256) sy += mask_value<T, VT>(m[y]);                // mask[b, 0, y]
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         sx += __shfl_down(sx, off);
@@ -940,24 +1037,44 @@ static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStrea
 }
 
 template <int NW, int DEPTH>
-static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, size_t lds, hipStream_t s) {
+static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, size_t lds, hipStream_t s) {
     dim3 grid(p.B), block(NW * 128);
-    if (vec) {
-        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 0>, grid, block, lds, s, p);
-        return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 1>, grid, block, lds, s, p);
+    if (vt != VT_F32) {
+        // 16-bit scores: 16-byte loaders only (the caller routes everything else to the generic kernel),
+        // and only the two wide workgroup shapes are built (narrow text runs on NW = 4 with idle waves)
+        if (NW >= 4) {
+            if (vt == VT_BF16) {
+                if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 0, VT_BF16>, grid, block, lds, s, p);
+                return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 1, VT_BF16>, grid, block, lds, s, p);
+            }
+            if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 0, VT_F16>, grid, block, lds, s, p);
+            return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 1, VT_F16>, grid, block, lds, s, p);
+        }
+        return fail(ALIGNER_EINVAL, "internal: 16-bit scores on a narrow workgroup");
     }
-    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 0>, grid, block, lds, s, p);
-    return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 1>, grid, block, lds, s, p);
+    if (vec) {
+        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 0, VT_F32>, grid, block, lds, s, p);
+        return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 1, VT_F32>, grid, block, lds, s, p);
+    }
+    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 0, VT_F32>, grid, block, lds, s, p);
+    return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 1, VT_F32>, grid, block, lds, s, p);
+}
+
+template <int R, int VT>
+static int launch_generic_vt(MaxpathParams p, int maskmode, size_t lds, hipStream_t s) {
+    dim3 grid(p.B), block(256);
+    if (maskmode == 0) return launch_with_lds(maxpath_generic_kernel<R, 0, VT>, grid, block, lds, s, p);
+    return launch_with_lds(maxpath_generic_kernel<R, 1, VT>, grid, block, lds, s, p);
 }
 
 template <int R>
-static int launch_generic(MaxpathParams p, int maskmode, size_t lds, hipStream_t s) {
-    dim3 grid(p.B), block(256);
-    if (maskmode == 0) return launch_with_lds(maxpath_generic_kernel<R, 0>, grid, block, lds, s, p);
-    return launch_with_lds(maxpath_generic_kernel<R, 1>, grid, block, lds, s, p);
+static int launch_generic(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
+    if (vt == VT_BF16) return launch_generic_vt<R, VT_BF16>(p, maskmode, lds, s);
+    if (vt == VT_F16) return launch_generic_vt<R, VT_F16>(p, maskmode, lds, s);
+    return launch_generic_vt<R, VT_F32>(p, maskmode, lds, s);
 }
 
-static int forward_impl(const float *value, const void *mask, int mask_dtype, const int32_t *t_xs,
+static int forward_impl(const void *value, int value_dtype, const void *mask, int mask_dtype, const int32_t *t_xs,
                         const int32_t *t_ys, int32_t *tok_out, int32_t *dur_out, void *ws,
                         size_t ws_bytes, int B, int Tx, int Ty, float neg, int flags, hipStream_t s) {
     if (!value || !ws) return fail(ALIGNER_EINVAL, "value/workspace pointer is null");
@@ -968,8 +1085,12 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
         return fail(ALIGNER_EINVAL, "need either lengths (t_xs,t_ys) or a mask to derive them from");
     if ((flags & ALIGNER_F_STRICT_MASK) && !mask)
         return fail(ALIGNER_EINVAL, "ALIGNER_F_STRICT_MASK needs a mask");
-    if ((flags & ALIGNER_F_STRICT_MASK) && mask_dtype != ALIGNER_DT_F32)
-        return fail(ALIGNER_EINVAL, "strict mask must be fp32 (dtype %d)", mask_dtype);
+    const int vt = value_dtype == ALIGNER_DT_F32 ? VT_F32 : value_dtype == ALIGNER_DT_BF16 ? VT_BF16
+                 : value_dtype == ALIGNER_DT_F16 ? VT_F16 : -1;
+    if (vt < 0) return fail(ALIGNER_EINVAL, "value dtype %d not supported (F32, BF16, F16)", value_dtype);
+    if ((flags & ALIGNER_F_STRICT_MASK) && mask_dtype != value_dtype)
+        return fail(ALIGNER_EINVAL, "strict mask must have the scores' dtype (mask %d, value %d): the product is "
+                                    "rounded in that dtype like torch's value * mask", mask_dtype, value_dtype);
     if (B == 0) return ALIGNER_OK;
     const WsLayout L = ws_layout(B, Tx, Ty);
     if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
@@ -999,13 +1120,14 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
-    const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
+    const int per16 = vt == VT_F32 ? 4 : 8;                      // scores per 16-byte load
+    const bool vec = (Ty % per16 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
                      (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
                      (size_t)Tx * (size_t)Ty * 4 < (1ull << 31);
 
     const int nw_need = (Tx + RPW - 1) / RPW;
-    if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8) {
-        const int NW = nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
+    if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8 && (vt == VT_F32 || vec)) {
+        const int NW = (nw_need <= 4 && vt != VT_F32) ? 4 : nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
         const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * RING_LD) * 4 + 16, 16);
         if (fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = 0;
@@ -1030,10 +1152,10 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
             }
             if (lds) {
                 switch (NW) {
-                    case 1: return launch_pipelined<1, 4>(p, vec, maskmode, lds, s);
-                    case 2: return launch_pipelined<2, 4>(p, vec, maskmode, lds, s);
-                    case 4: return launch_pipelined<4, 2>(p, vec, maskmode, lds, s);
-                    default: return launch_pipelined<8, 2>(p, vec, maskmode, lds, s);
+                    case 1: return launch_pipelined<1, 4>(p, vec, maskmode, vt, lds, s);
+                    case 2: return launch_pipelined<2, 4>(p, vec, maskmode, vt, lds, s);
+                    case 4: return launch_pipelined<4, 2>(p, vec, maskmode, vt, lds, s);
+                    default: return launch_pipelined<8, 2>(p, vec, maskmode, vt, lds, s);
                 }
             }
         }
@@ -1048,10 +1170,10 @@ static int forward_impl(const float *value, const void *mask, int mask_dtype, co
     size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
     if (lds < fwd) lds = fwd;
     switch (RR) {
-        case 1: return launch_generic<1>(p, maskmode, lds, s);
-        case 2: return launch_generic<2>(p, maskmode, lds, s);
-        case 4: return launch_generic<4>(p, maskmode, lds, s);
-        default: return launch_generic<8>(p, maskmode, lds, s);
+        case 1: return launch_generic<1>(p, maskmode, vt, lds, s);
+        case 2: return launch_generic<2>(p, maskmode, vt, lds, s);
+        case 4: return launch_generic<4>(p, maskmode, vt, lds, s);
+        default: return launch_generic<8>(p, maskmode, vt, lds, s);
     }
 }
 
@@ -1112,18 +1234,34 @@ int aligner_lengths_from_mask(const void *mask, int mask_dtype, int B, int Tx, i
             hipLaunchKernelGGL(lengths_kernel<int>, dim3(B), dim3(256), 0, s,
                                static_cast<const int *>(mask), Tx, Ty, t_xs, t_ys);
             break;
+        case ALIGNER_DT_BF16:
+            hipLaunchKernelGGL((lengths_kernel<unsigned short, VT_BF16>), dim3(B), dim3(256), 0, s,
+                               static_cast<const unsigned short *>(mask), Tx, Ty, t_xs, t_ys);
+            break;
+        case ALIGNER_DT_F16:
+            hipLaunchKernelGGL((lengths_kernel<unsigned short, VT_F16>), dim3(B), dim3(256), 0, s,
+                               static_cast<const unsigned short *>(mask), Tx, Ty, t_xs, t_ys);
+            break;
         default:
-            return fail(ALIGNER_EINVAL, "mask dtype %d not supported (use F32, U8 or I32)", mask_dtype);
+            return fail(ALIGNER_EINVAL, "mask dtype %d not supported (use F32, BF16, F16, U8 or I32)", mask_dtype);
     }
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
+}
+
+int aligner_maxpath_forward(const void *value, int value_dtype, const void *mask, int mask_dtype,
+                            const int32_t *t_xs, const int32_t *t_ys, int32_t *tok_out,
+                            int32_t *dur_out, void *ws, size_t ws_bytes, int B, int Tx, int Ty,
+                            float max_neg_val, int flags, void *stream) {
+    return forward_impl(value, value_dtype, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
+                        max_neg_val, flags, static_cast<hipStream_t>(stream));
 }
 
 int aligner_maxpath_forward_f32(const float *value, const void *mask, int mask_dtype,
                                 const int32_t *t_xs, const int32_t *t_ys, int32_t *tok_out,
                                 int32_t *dur_out, void *ws, size_t ws_bytes, int B, int Tx, int Ty,
                                 float max_neg_val, int flags, void *stream) {
-    return forward_impl(value, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
+    return forward_impl(value, ALIGNER_DT_F32, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
                         max_neg_val, flags, static_cast<hipStream_t>(stream));
 }
 
@@ -1137,16 +1275,24 @@ int aligner_maxpath_expand(const void *ws, void *path, int path_dtype, int B, in
     return expand_impl(starts, path, path_dtype, B, Tx, Ty, static_cast<hipStream_t>(stream));
 }
 
+int aligner_maxpath(const void *value, int value_dtype, const void *mask, int mask_dtype, const int32_t *t_xs,
+                    const int32_t *t_ys, void *path_out, int path_dtype, int32_t *tok_out,
+                    int32_t *dur_out, void *ws, size_t ws_bytes, int B, int Tx, int Ty,
+                    float max_neg_val, int flags, void *stream) {
+    if (path_out && dtype_size(path_dtype) == 0)
+        return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    int rc = forward_impl(value, value_dtype, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
+                          max_neg_val, flags, static_cast<hipStream_t>(stream));
+    if (rc || !path_out || B == 0) return rc;
+    return aligner_maxpath_expand(ws, path_out, path_dtype, B, Tx, Ty, stream);
+}
+
 int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, const int32_t *t_xs,
                         const int32_t *t_ys, void *path_out, int path_dtype, int32_t *tok_out,
                         int32_t *dur_out, void *ws, size_t ws_bytes, int B, int Tx, int Ty,
                         float max_neg_val, int flags, void *stream) {
-    if (path_out && dtype_size(path_dtype) == 0)
-        return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
-    int rc = forward_impl(value, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
-                          max_neg_val, flags, static_cast<hipStream_t>(stream));
-    if (rc || !path_out || B == 0) return rc;
-    return aligner_maxpath_expand(ws, path_out, path_dtype, B, Tx, Ty, stream);
+    return aligner_maxpath(value, ALIGNER_DT_F32, mask, mask_dtype, t_xs, t_ys, path_out, path_dtype, tok_out, dur_out,
+                           ws, ws_bytes, B, Tx, Ty, max_neg_val, flags, stream);
 }
 
 int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {

@@ -25,6 +25,9 @@ _TORCH_TO_DT = {
     torch.bool: _lib.DT_U8, torch.int64: _lib.DT_I64,
 }
 
+# score dtypes the kernels read directly (16-bit ones are up-cast inside the loaders: no conversion pass)
+_SCORE_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
+
 _workspaces = _lib.StreamWorkspaces(zero=True)     # status word: zero at allocation, sticky afterwards
 
 
@@ -62,7 +65,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           out_path: Optional[torch.Tensor] = None) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
-    value [B,Tx,Ty] float (computed in fp32 like the reference, __init__.py:14);
+    value [B,Tx,Ty] float (computed in fp32 like the reference, __init__.py:14; fp32, bf16 and fp16 tensors are
+    read as they are, other dtypes are cast to fp32 first);
     lengths either as int32 vectors t_x/t_y [B] or derived from `mask`
     (__init__.py:18-19).  With strict_mask the scores are first multiplied by the
     mask element-wise (__init__.py:11).  Asynchronous on the current stream.
@@ -76,19 +80,23 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
     lib = _lib.load()
     with torch.no_grad(), torch.cuda.device(device):
         v = value.detach()
-        if v.dtype != torch.float32:
-            v = v.float()
-        if not v.is_contiguous():
-            v = v.contiguous()
         m = None
         mdt = 0
         if mask is not None:
             if mask.shape != value.shape:
                 raise ValueError("mask and value must have the same shape")
             m = mask.detach()
-            if strict_mask and m.dtype != torch.float32:
-                m = m.float()
-            if m.dtype not in (torch.float32, torch.uint8, torch.bool, torch.int32):
+        if strict_mask and m is not None and (m.dtype != v.dtype or v.dtype not in _SCORE_DTYPES):
+            # torch's type promotion decides the dtype the product is rounded in: take the product exactly as
+            # the reference does (__init__.py:11); the mask then only supplies the lengths
+            v = v * m
+            strict_mask = False
+        if v.dtype not in _SCORE_DTYPES:
+            v = v.float()                   # fp64 / integer scores: the reference's astype(np.float32)
+        if not v.is_contiguous():
+            v = v.contiguous()
+        if m is not None:
+            if m.dtype not in (torch.float32, torch.bfloat16, torch.float16, torch.uint8, torch.bool, torch.int32):
                 m = m.float()
             if not m.is_contiguous():
                 m = m.contiguous()
@@ -128,8 +136,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     (_lib.F_COMPAT_TXGTTY if compat_tx_gt_ty else 0) | \
                     (_lib.F_FORCE_GENERIC if force_generic else 0) | \
                     (_lib.F_NO_PREV_TABLE if no_prev_table else 0)
-            _lib.check(lib.aligner_maxpath_f32(
-                v.data_ptr(), _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
+            _lib.check(lib.aligner_maxpath(
+                v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
                 ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))
         else:
             for t in (path, tok, dur):

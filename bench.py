@@ -146,37 +146,33 @@ def event_time_us(fn, iters: int, dev) -> float:
     return s.elapsed_time(e) / iters * 1e3
 
 
-def cpu_baseline(seconds: float = 12.0):
-    """The reference's maximum_path_c on the host, 1 thread (the reference ships
-    serial: setup.py passes no -fopenmp), on the same [64,200,1000] workload shape."""
+def cpu_baseline(dev, seconds: float = 12.0):
+    """The reference's maximum_path_c on the host, 1 thread (the reference ships serial: setup.py passes no
+    -fopenmp), on the same [64,200,1000] workload shape -- through oracle/libmaxpath_oracle.so, the C
+    restatement of core.pyx:7-45 that is pinned bit-for-bit to the reference's outputs (same loops, same
+    -O2 / no fast-math flags).  No compiled form of the reference travels to the GPU box."""
     from oracle import maxpath_oracle as O
     value = synth.synth_value(*synth.CONFIGS["C2"])
     tx = np.full(B, TX, np.int32)
     ty = np.full(B, TY, np.int32)
-    ref = None
-    try:
-        ref = O.load_ref()
-    except Exception:  # noqa: BLE001
-        ref = None
-    kind = "reference" if ref is not None else "port"
-    fn = ref.maximum_path_c if ref is not None else O.maximum_path_c
     paths = np.zeros(value.shape, np.int32)
     work = value.copy()
-    fn(paths, work, tx, ty)                               # warm-up
+    O.maximum_path_c(paths, work, tx, ty)                 # warm-up
     reps, spent = 0, 0.0
     while spent < seconds and reps < 2000:
         np.copyto(work, value)                            # fresh scores, outside the timer
         paths.fill(0)
         t0 = time.perf_counter()
-        fn(paths, work, tx, ty)
+        O.maximum_path_c(paths, work, tx, ty)
         spent += time.perf_counter() - t0
         reps += 1
     ups = B * reps / spent
-    out = {"value": round(ups, 1), "unit": "utterances/s", "cores": 1, "kind": kind,
-           "sample": f"maximum_path_c core on [64,200,1000] fp32 scores, {reps} batches in {spent:.1f}s "
-                     f"({spent / reps * 1e3:.1f} ms/batch), host has {os.cpu_count()} logical cores",
+    out = {"value": round(ups, 1), "unit": "utterances/s", "cores": 1, "kind": "port",
+           "sample": f"maximum_path_c core (C restatement, oracle/maxpath_oracle.c) on [64,200,1000] fp32 scores, "
+                     f"{reps} batches in {spent:.1f}s ({spent / reps * 1e3:.1f} ms/batch), host has "
+                     f"{os.cpu_count()} logical cores",
            "frames_per_s": round(ups * TY, 1)}
-    # secondary line (SURVEY 8d): what `prange` (core.pyx:44) would give if the reference were built with
+    # secondary line 1 (SURVEY 8d): what `prange` (core.pyx:44) would give if the reference were built with
     # -fopenmp -- the C restatement's OpenMP batch loop, one thread per utterance at most, ~4 s
     try:
         nthr = max(1, min(B, os.cpu_count() or 1))
@@ -193,6 +189,28 @@ def cpu_baseline(seconds: float = 12.0):
                             "sample": f"OpenMP batch loop of the C restatement, {r2} batches in {s2:.1f}s"}
     except Exception as e:  # noqa: BLE001
         out["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+    # secondary line 2: "wrapper-equivalent" -- what a caller of the reference's maximum_path(value,
+    # mask) pays end to end for GPU-resident tensors: the mask multiply, 2 x D2H and 1 x H2D of the [B,Tx,Ty]
+    # tensor, the host casts / allocations and the serial core (__init__.py:11-21), restated in
+    # oracle.maximum_path on top of the same C core
+    try:
+        v_dev = torch.from_numpy(value).to(dev)
+        m_dev = torch.ones_like(v_dev)
+        O.maximum_path(v_dev, m_dev)
+        torch.cuda.synchronize(dev)
+        r3, s3 = 0, 0.0
+        while s3 < 4.0 and r3 < 200:
+            t0 = time.perf_counter()
+            O.maximum_path(v_dev, m_dev)
+            torch.cuda.synchronize(dev)
+            s3 += time.perf_counter() - t0
+            r3 += 1
+        out["wrapper_equivalent"] = {"value": round(B * r3 / s3, 1), "unit": "utterances/s", "cores": 1, "kind": "port",
+                                     "sample": f"maximum_path(value, mask) with GPU tensors as the reference wrapper "
+                                               f"runs it (2 x D2H + H2D of 51.2 MB, host casts, serial core): "
+                                               f"{r3} calls in {s3:.1f}s ({s3 / r3 * 1e3:.1f} ms/call)"}
+    except Exception as e:  # noqa: BLE001
+        out["wrapper_equivalent"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 
@@ -204,6 +222,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured HIP graph")
     ap.add_argument("--gather-every", type=int, default=16, help="steps per duration all-gather bucket (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repeats", dest="repeats", action="store_false",
+                    help="skip the four extra timed regions (spread) and the one-batch-in-flight figure")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
     args = ap.parse_args()
@@ -262,14 +282,15 @@ def main():
         st.capture()
     step = steps[0]
 
-    def run(nsteps: int):
+    def run(nsteps: int, ns: int = 0):
+        ns = ns or nstreams                        # batches in flight for this run (serial figure: 1)
         main = torch.cuda.current_stream(dev)
         for strm in streams:
             strm.wait_stream(main)
         if dist is None:
             for i in range(nsteps):
-                with torch.cuda.stream(streams[i % nstreams]):
-                    steps[i % nstreams]()
+                with torch.cuda.stream(streams[i % ns]):
+                    steps[i % ns]()
         else:
             for i in range(nsteps):
                 k, bi, slot = i % nstreams, (i // ge) % 2, i % ge
@@ -290,22 +311,34 @@ def main():
         if dist is not None:
             main.wait_stream(comm_stream)
 
+    def timed(nsteps: int, ns: int = 0) -> float:
+        """EXACTLY nsteps steps bracketed by barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(nsteps, ns)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     run(args.warmup)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(args.steps)                    # the reported figure: one region of exactly K steps
+    # spread of that figure: the same region four more times (not part of `value`)
+    extra = [timed(args.steps) for _ in range(4)] if args.repeats else []
+    # strictly serial steps (one batch in flight: what a training step that waits for its alignment sees)
+    serial_elapsed = None
+    if dist is None and args.repeats:
+        run(min(args.warmup, 10), 1)
+        serial_elapsed = float(np.median([timed(args.steps, 1) for _ in range(3)]))
 
     # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
     for st in steps:
@@ -334,16 +367,20 @@ def main():
         }
         dom = max(kernels, key=lambda k: kernels[k]["us"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
-        # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes of this
-        # same command, gfx950 correction applied; see the note in the file) -- not measured by this run
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01d_pmc_hbm_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
+        # command (tools/pmc_traffic.py; gfx950 FETCH_SIZE correction applied) and committed under profiles/ --
+        # not measured by this run, so the line names the file (and with it the build) the figure comes from
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_hbm_traffic.json",):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
+                traffic_src = "profiles/" + name
+                break
+            except (OSError, ValueError, KeyError):
+                continue
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_us": round(kernels[dom]["us"], 2), "algorithmic_bytes": kernels[dom]["bytes"],
                     # the DP launches one 8-wave workgroup per utterance: waves resident / wave slots of the chip
                     "dp_wave_occupancy": round(B * 8 / (256 * 32), 4),
@@ -355,6 +392,10 @@ def main():
             "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * TY, 1),
             "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "ms_per_step_repeats": ([round(elapsed / args.steps * 1e3, 5)] +
+                                    [round(x / args.steps * 1e3, 5) for x in extra]) if extra else None,
+            "ms_per_step_median": round(float(np.median([elapsed] + extra)) / args.steps * 1e3, 5) if extra else None,
+            "serial_ms_per_step": round(serial_elapsed / args.steps * 1e3, 5) if serial_elapsed else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: similarity (L2, C=80) + monotonic alignment search, "
@@ -367,7 +408,7 @@ def main():
             "roofline": roofline,
         }
         if n == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(dev)
             out["speedup_vs_cpu_1thread"] = round(ups / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALIGNER_ABI_VERSION 1
+#define ALIGNER_ABI_VERSION 2
 
 /* error codes */
 #define ALIGNER_OK       0
@@ -95,7 +95,7 @@ int aligner_lengths_from_mask(const void *mask_dev, int mask_dtype,
  *
  *   value_dev   [B,Tx,Ty] fp32, NOT modified (the reference mutates its private
  *               host copy; the caller's tensor is untouched there too).
- *   mask_dev    optional [B,Tx,Ty] of mask_dtype (F32 or U8).  Used (a) to derive
+ *   mask_dev    optional [B,Tx,Ty] of mask_dtype (F32, BF16, F16, U8 or I32).  Used (a) to derive
  *               lengths when t_xs_dev/t_ys_dev are NULL and (b) for the
  *               element-wise multiply when ALIGNER_F_STRICT_MASK is set.
  *   t_xs_dev,t_ys_dev  optional [B] int32 lengths; when NULL they are derived
@@ -107,6 +107,28 @@ int aligner_lengths_from_mask(const void *mask_dev, int mask_dtype,
  *   dur_out_dev optional [B,Tx] int32: frames per token (= path.sum(2)).
  *   max_neg_val core.pyx:40 (default -1e9 in the reference).
  */
+/* The same for scores of `value_dtype` F32, BF16 or F16: 16-bit scores are up-cast to fp32 (exactly) inside the
+ * kernels' loaders -- no conversion pass, half the read traffic -- and the DP runs in fp32 like the reference
+ * (__init__.py:14).  With ALIGNER_F_STRICT_MASK the mask must have the scores' dtype: the product is rounded in
+ * that dtype, as torch's `value * mask` (__init__.py:11) is.  16-byte aligned pointers and Ty % 8 == 0 take the
+ * fast kernels, anything else the generic one. */
+int aligner_maxpath(const void *value_dev, int value_dtype,
+                    const void *mask_dev, int mask_dtype,
+                    const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                    void *path_out_dev, int path_dtype,
+                    int32_t *tok_out_dev, int32_t *dur_out_dev,
+                    void *workspace_dev, size_t workspace_bytes,
+                    int B, int Tx, int Ty,
+                    float max_neg_val, int flags, void *stream);
+int aligner_maxpath_forward(const void *value_dev, int value_dtype,
+                            const void *mask_dev, int mask_dtype,
+                            const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                            int32_t *tok_out_dev, int32_t *dur_out_dev,
+                            void *workspace_dev, size_t workspace_bytes,
+                            int B, int Tx, int Ty,
+                            float max_neg_val, int flags, void *stream);
+
+/* fp32 scores (value_dtype = ALIGNER_DT_F32). */
 int aligner_maxpath_f32(const float *value_dev,
                         const void *mask_dev, int mask_dtype,
                         const int32_t *t_xs_dev, const int32_t *t_ys_dev,

@@ -273,6 +273,47 @@ def test_strict_mask_and_wrapper_semantics(golden_dir, dev):
     assert r.device.type == "cpu" and np.array_equal(r.numpy().astype(np.int8), z["path_f32"])
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_sixteen_bit_scores_read_directly(appendix_a, dev, dt):
+    """bf16 / fp16 scores go straight into the DP's loaders (no up-cast pass): same path as the fp32 up-cast.
+    BASELINE config C5 ("bf16 similarity + int32 path", [8,500,4000], scores exactly representable in bf16 and
+    fp16) against the reference's hash; ragged random batches, an odd T_mel (generic kernel) and the strict
+    mask product -- rounded in the tensors' dtype, as torch's value * mask is -- against the oracle."""
+    import aligner_amd
+    rec, _ = appendix_a
+    v = torch.from_numpy(synth.synth_value(*synth.CONFIGS["C5"]))
+    assert torch.equal(v.to(dt).float(), v)                      # exactly representable: the golden hash applies
+    r = aligner_amd.align(v.to(dt).to(dev), torch.full((8,), 500, dtype=torch.int32, device=dev),
+                          torch.full((8,), 4000, dtype=torch.int32, device=dev), path_dtype=torch.int32)
+    torch.cuda.synchronize()
+    assert synth.sha256_of(r.path.cpu().numpy()) == rec["C5-longform"]["path_sha256"]
+    assert synth.sha256_of(r.durations.cpu().numpy().astype(np.int32)) == rec["C5-longform"]["dur_sha256"]
+    rng = np.random.default_rng(5)
+    for (B, Tx, Ty) in [(5, 200, 1000), (3, 70, 264), (2, 300, 808), (3, 33, 131), (2, 130, 999)]:
+        v = torch.from_numpy(rng.standard_normal((B, Tx, Ty)).astype(np.float32) * 3).to(dt)
+        if Tx == 70:
+            v[0, 3, 5] = float("nan")                            # the exact-sweep fallback with 16-bit scores
+            v[1, 10, 40] = float("inf")
+        ty = rng.integers(Tx, Ty + 1, B).astype(np.int32)
+        tx = np.array([rng.integers(1, Tx + 1) for _ in ty], np.int32)
+        tx[0], ty[0] = Tx, Ty
+        want = _oracle_path(v.float().numpy(), tx, ty)
+        for kw in ({}, {"no_prev_table": True}, {"force_generic": True}):
+            r = aligner_amd.align(v.to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
+                                  path_dtype=torch.int32, **kw)
+            torch.cuda.synchronize()
+            assert np.array_equal(r.path.cpu().numpy(), want), (B, Tx, Ty, kw)
+        # strict mask in the scores' dtype, with values that are not 0/1: the product is rounded in that dtype
+        mask = torch.from_numpy(synth.prefix_mask(tx, ty, Tx, Ty)).to(dt) * torch.from_numpy(
+            rng.uniform(0.5, 1.5, (B, Tx, Ty)).astype(np.float32)).to(dt)
+        mask[:, :, 0] = torch.from_numpy(synth.prefix_mask(tx, ty, Tx, Ty))[:, :, 0].to(dt)   # lengths are read from
+        mask[:, 0, :] = torch.from_numpy(synth.prefix_mask(tx, ty, Tx, Ty))[:, 0, :].to(dt)   # column 0 / row 0
+        want = _oracle_path((v * mask).float().numpy(), tx, ty)
+        got = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        assert got.dtype == dt
+        assert np.array_equal(got.float().cpu().numpy().astype(np.int32), want), (B, Tx, Ty, "strict")
+
+
 def test_maximum_path_c_numpy_boundary(kats, dev):
     """core.pyx:40 signature on host buffers, through aligner_maxpath_host_f32."""
     import aligner_amd

@@ -33,6 +33,6 @@ print("per-wave fwd_done (b=0):", [int(s[0, w, 1] - s[0, 0, 0]) for w in range(n
 start = s[:, 0, 0]
 for w in range(nw):
     r = s[0, w]
-    if r[8] > 0: print(f"wave {w}: tile10 stamps rel to 8:", [int(r[k] - r[8]) for k in (9, 10, 11, 12)])
-print("chunk-done stamps rel. to win_loaded (b=0..3), chunks 3,2,1,0:", [[int(s[b, 0, 8 + c] - s[b, 0, 2]) for c in (3, 2, 1, 0)] for b in range(min(B, 4))])
+    if r[8] > 0: print(f"wave {w}: tile-10 stamps: start {int(r[8] - s[0, 0, 0])}, then +", [int(r[k] - r[8]) for k in (9, 10, 11)],
+                       "(compute: sweep done, stores done, barrier passed; loader: LDS written, loads issued, barrier passed)")
 print("block start skew cycles: max-min", int(start.max() - start.min()))
