@@ -680,6 +680,161 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
 }
 
 // --------------------------------------------------------------------------
+// Exact-product form of the same front end: the contraction on v_mfma_f32_32x32x2_f32 (fp32 operands, fp32
+// fma chain -- no operand splitting), a quarter of the bf16x3 kernel's matrix rate.  The bf16x3 product
+// (hi*hi + hi*lo + lo*hi, lo itself rounded to bf16) carries ~2^-16.5 relative error per product; the logit
+// multiplies the summed products by 2*temperature (L2) or temperature (dot), so the 1e-4 bound on logp holds
+// for the default temperature with a wide margin but not for sharp ones on large encodings (measured 5e-4 at
+// temperature 0.05, |k|,|q| ~ 3 per channel).  Host rule (aligner_softattn): L2 with temperature > 0.002, or
+// dot with temperature > 0.2, takes this kernel; so does the "softattn_exact" debug option.
+// Plain structure (a correctness path): a workgroup = 4 waves = 128 frames of one utterance; text rows in
+// groups of GE 32-row tiles staged to LDS as fp32 A fragments; two sweeps over the groups (running max / sum,
+// then normalise and store), the contraction simply redone in the second.
+// --------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void softattn_exact_kernel(SoftAttnParams p, int GE) {
+    constexpr int S2 = 8 * KS;                                   // k-steps of 2 channels
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Af = reinterpret_cast<float *>(smem);                 // [GE][S2][64]: K[2s + (lane>>5)][32(r0+r) + (lane&31)]
+    float *kn = Af + (size_t)GE * S2 * 64;                       // [GE*32] row term (natural log units), -inf = masked
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int NQ = (p.Ty + 127) / 128;
+    const int b = blockIdx.x / NQ, fq = blockIdx.x % NQ;
+    const int col = fq * 128 + wave * 32 + (lane & 31);
+    const bool col_ok = col < p.Ty;
+    int tx = p.Tx;
+    if (p.t_xs) {
+        tx = p.t_xs[b];
+        tx = tx < 0 ? 0 : (tx > p.Tx ? p.Tx : tx);
+    }
+    const bool l2 = (p.sim == ALIGNER_SIM_L2);
+    const float scale = l2 ? -p.temperature : p.temperature;
+    const float *Kb = p.keys + (size_t)b * p.C * p.Tx;
+    const float *Qb = p.queries + (size_t)b * p.C * p.Ty;
+    // mel operand: B fragment k = 2s + half, column = this lane's frame
+    float qx[S2];
+    float qn = 0.f;
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+        const int c = 2 * s + half;
+        const float v = (c < p.C && col_ok) ? Qb[(size_t)c * p.Ty + col] : 0.f;
+        qx[s] = v;
+        qn = fmaf(v, v, qn);
+    }
+    qn += __shfl_xor(qn, 32);
+    const int RT = (p.Tx + 31) / 32, NG = (RT + GE - 1) / GE;
+    auto stage = [&](int g) {
+        const int r0 = GE * g;
+        for (int idx = tid; idx < GE * S2 * 64; idx += 256) {
+            const int ln = idx & 63, sr = idx >> 6, st = sr % S2, r = sr / S2;
+            const int i = 32 * (r0 + r) + (ln & 31), c = 2 * st + (ln >> 5);
+            Af[idx] = (i < p.Tx && c < p.C) ? Kb[(size_t)c * p.Tx + i] : 0.f;
+        }
+        for (int il = tid; il < GE * 32; il += 256) {
+            const int i = 32 * r0 + il;
+            float v = NEG_INF_F;
+            if (i < tx) {
+                v = 0.f;
+                if (l2) {
+                    float nrm = 0.f;
+                    for (int c = 0; c < p.C; ++c) { const float k = Kb[(size_t)c * p.Tx + i]; nrm = fmaf(k, k, nrm); }
+                    v = scale * nrm;
+                }
+            }
+            kn[il] = v;
+        }
+    };
+    auto logits = [&](float (&lg)[16], int r) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float *A = Af + (size_t)r * S2 * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s * 64], qx[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int il = 32 * r + (e & 3) + 8 * (e >> 2) + 4 * half;
+            lg[e] = l2 ? fmaf(acc[e], -2.0f * scale, kn[il] + scale * qn) : fmaf(acc[e], scale, kn[il]);
+        }
+    };
+    float m_run = NEG_INF_F, l_run = 0.f;
+    for (int g = 0; g < NG; ++g) {
+        __syncthreads();
+        stage(g);
+        __syncthreads();
+        const int nt = (RT - GE * g < GE) ? RT - GE * g : GE;
+        for (int r = 0; r < nt; ++r) {
+            float lg[16];
+            logits(lg, r);
+            float tm = m_run;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tm = fmaxf(tm, lg[e]);
+            if (tm != NEG_INF_F) {
+                float ls = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ls += __expf(lg[e] - tm);
+                l_run = (m_run == NEG_INF_F ? 0.f : l_run * __expf(m_run - tm)) + ls;
+                m_run = tm;
+            }
+        }
+    }
+    float lse;
+    {
+        const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
+        const float m_all = fmaxf(m_run, m_o);
+        const float m_fin = (m_all == NEG_INF_F) ? 0.f : m_all;
+        const float l_all = (m_run == NEG_INF_F ? 0.f : l_run * __expf(m_run - m_fin)) +
+                            (m_o == NEG_INF_F ? 0.f : l_o * __expf(m_o - m_fin));
+        lse = m_fin + __logf(l_all);
+    }
+    // with a prior the soft output needs a second normalisation: running max / sum of the final log-probs
+    float m2 = NEG_INF_F, l2s = 0.f;
+    const int npass = (p.soft && p.prior) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        float lse2 = 0.f;
+        if (pass == 1) {
+            const float m_o = __shfl_xor(m2, 32), l_o = __shfl_xor(l2s, 32);
+            const float m_all = fmaxf(m2, m_o);
+            const float m_fin = (m_all == NEG_INF_F) ? 0.f : m_all;
+            lse2 = m_fin + __logf((m2 == NEG_INF_F ? 0.f : l2s * __expf(m2 - m_fin)) +
+                                  (m_o == NEG_INF_F ? 0.f : l_o * __expf(m_o - m_fin)));
+        }
+        for (int g = 0; g < NG; ++g) {
+            __syncthreads();
+            stage(g);
+            __syncthreads();
+            const int nt = (RT - GE * g < GE) ? RT - GE * g : GE;
+            for (int r = 0; r < nt; ++r) {
+                float lg[16];
+                logits(lg, r);
+                const int i_lane = 32 * (GE * g + r) + 4 * half;
+                const size_t lane_off = ((size_t)b * p.Tx + i_lane) * p.Ty + col;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int iu = (e & 3) + 8 * (e >> 2);
+                    const bool ok = (i_lane + iu < p.Tx) && col_ok;
+                    float v = lg[e] - lse;
+                    if (p.prior && ok) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
+                    if (pass == 0) {
+                        if (ok) {
+                            p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                            if (p.soft && !p.prior) p.soft[lane_off + (size_t)iu * p.Ty] = __expf(v);
+                        }
+                        if (npass == 2 && ok && v != NEG_INF_F) {
+                            const float mn = fmaxf(m2, v);
+                            l2s = (m2 == NEG_INF_F ? 0.f : l2s * __expf(m2 - mn)) + __expf(v - mn);
+                            m2 = mn;
+                        }
+                    } else if (ok) {
+                        p.soft[lane_off + (size_t)iu * p.Ty] = __expf(v - lse2);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
 // 1-D convolution of the text / mel encoders ("same" zero padding, K odd) on the matrix cores:
 // y[b,o,t] = act(bias[o] + sum_{i,k} w[o,i,k] x[b,i,t+k-K/2]) as a GEMM with
 // M = out channels, N = frames, reduction over (in channel, tap).  fp32-input MFMA
@@ -1269,6 +1424,21 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
     return ALIGNER_OK;
 }
 
+template <int KS>
+static int launch_softattn_exact(const SoftAttnParams &p, hipStream_t s) {
+    const size_t per_tile = (size_t)8 * KS * 64 * sizeof(float);
+    const int RT = (p.Tx + 31) / 32;
+    int GE = (int)((60 * 1024) / per_tile);
+    GE = GE < 1 ? 1 : (GE > RT ? RT : GE);
+    const size_t lds = GE * per_tile + (size_t)GE * 32 * sizeof(float);
+    auto kern = softattn_exact_kernel<KS>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    dim3 grid((unsigned)((p.Ty + 127) / 128) * (unsigned)p.B), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p, GE);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
 }  // namespace aligner
 
 using namespace aligner;
@@ -1296,11 +1466,19 @@ int aligner_softattn_f32(const float *keys, const float *queries, const int32_t 
                      reinterpret_cast<const uint4 *>(ws + L.hi_off), reinterpret_cast<const uint4 *>(ws + L.lo_off),
                      reinterpret_cast<const float *>(ws + L.kn_off), L.RT, g_debug_stamps, B, C, Tx, Ty, temperature,
                      sim};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // sharp temperatures multiply the bf16x3 product error past the 1e-4 bound: exact fp32 products instead
+    // (rule and reasoning: softattn_exact_kernel)
+    const bool sharp = (sim == ALIGNER_SIM_L2) ? temperature > 0.002f : temperature > 0.2f;
+    if (sharp || g_opt_softattn_exact) {
+        if (L.KS == 5) return launch_softattn_exact<5>(p, s);
+        if (L.KS == 8) return launch_softattn_exact<8>(p, s);
+        return launch_softattn_exact<16>(p, s);
+    }
     const int G = L.KS <= 8 ? 7 : 4;
     const bool multi = L.RT > G;
     if (soft_out && prior && multi)
         return fail(ALIGNER_EDOM, "soft output with a prior needs Tx <= %d", 32 * G);
-    hipStream_t s = static_cast<hipStream_t>(stream);
     if (L.KS == 5) return multi ? launch_softattn<5, 7, true>(p, ws, L, s) : launch_softattn<5, 7, false>(p, ws, L, s);
     if (L.KS == 8) return multi ? launch_softattn<8, 7, true>(p, ws, L, s) : launch_softattn<8, 7, false>(p, ws, L, s);
     return multi ? launch_softattn<16, 4, true>(p, ws, L, s) : launch_softattn<16, 4, false>(p, ws, L, s);

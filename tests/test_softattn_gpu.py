@@ -66,6 +66,33 @@ def test_logp_only_path(dev, B, C, Tx, Ty):
     assert none is None and _cmp(got, want) < TOL
 
 
+@pytest.mark.parametrize("B,C,Tx,Ty,sim", [(2, 80, 50, 130, "l2"), (3, 80, 200, 333, "l2"), (2, 16, 7, 40, "l2"),
+                                           (2, 80, 224, 129, "dot"), (1, 80, 300, 257, "l2"), (1, 200, 130, 64, "l2"),
+                                           (2, 128, 500, 260, "dot")])
+def test_exact_product_kernel_matches_oracle(dev, request, B, C, Tx, Ty, sim):
+    """The fp32-MFMA form of the front end (taken for sharp temperatures; forced here through the debug option)
+    on the same shapes as the bf16x3 kernels: log-probs, soft output, ragged text, with and without a prior."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from oracle import softattn_oracle as S
+    _lib.check(_lib.load().aligner_debug_set_option(b"softattn_exact", 1))
+    request.addfinalizer(lambda: _lib.load().aligner_debug_set_option(b"softattn_exact", 0))
+    g = torch.Generator().manual_seed(B * 77 + Tx)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    t_x[0] = Tx
+    prior = torch.rand(B, Tx, Ty, generator=g)
+    temp = 0.0005 if sim == "l2" else 0.11
+    for pr in (None, prior):
+        want, want_soft = S.soft_attention(k, q, t_x=t_x, prior=pr, temperature=temp, sim=sim)
+        got, soft = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev), temperature=temp, sim=sim,
+                                               prior=None if pr is None else pr.to(dev), want_soft=True)
+        torch.cuda.synchronize()
+        assert _cmp(got, want) < TOL
+        assert (soft.cpu() - want_soft).abs().max().item() < TOL
+
+
 def _oracle_per_utterance(k, q, t_x, **kw):
     """The oracle evaluated one utterance at a time (its [B,C,Tx,Ty] difference tensor is 4 GB at B = 64)."""
     from oracle import softattn_oracle as S
@@ -105,8 +132,10 @@ def test_prior_and_sharp_temperature(dev):
         got, soft = aligner_amd.soft_attention(k.to(dev), q.to(dev), t_x=t_x.to(dev), prior=prior.to(dev),
                                                temperature=temp, want_soft=True)
         torch.cuda.synchronize()
-        assert _cmp(got, want, 5e-4) < 5e-4 if temp > 0.01 else _cmp(got, want) < TOL
-        assert (soft.cpu() - want_soft).abs().max().item() < 2e-4
+        # 1e-4 at the sharp temperature too (|logp| up to ~150 here): above temperature 0.002 the host takes the
+        # exact-product kernel (fp32 MFMA) instead of the bf16x3 one -- rule in aligner_softattn_f32
+        assert _cmp(got, want) < TOL
+        assert (soft.cpu() - want_soft).abs().max().item() < TOL
 
 
 def test_conv1d_and_full_encoder(dev):
