@@ -44,7 +44,7 @@ struct SoftAttnParams {
     const float *queries;   // [B,C,Ty]
     const int   *t_xs;      // nullable
     const float *prior;     // nullable [B,Tx,Ty]
-    float *logp;            // [B,Tx,Ty]
+    float *logp;            // [B,Tx,Ty] fp32, or bf16 when out16 (same shape)
     float *soft;            // nullable
     const uint4 *frag_hi;   // [B][RT][KS][64] text operand, bf16 high halves in MFMA A-fragment order
     const uint4 *frag_lo;   // same, low halves
@@ -54,6 +54,7 @@ struct SoftAttnParams {
     int B, C, Tx, Ty;
     float temperature;
     int sim;
+    int out16;              // logp is written as bf16 (round to nearest even)
 };
 
 constexpr int SA_WAVES = 8;                       // waves per workgroup: 8 x 32 = 256 mel frames share one staged text operand
@@ -89,6 +90,12 @@ __device__ __forceinline__ void wait_regs8(float (&r)[8]) {       // CNT < 0: de
 __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
+}
+
+// one log-prob to logp[idx]: fp32, or bf16 (RNE) when the caller asked for 16-bit log-probs
+__device__ __forceinline__ void store_logp(const SoftAttnParams &p, size_t idx, float v) {
+    if (p.out16) reinterpret_cast<__bf16 *>(p.logp)[idx] = (__bf16)v;
+    else         p.logp[idx] = v;
 }
 
 // Text operand prep (once per utterance, not once per workgroup): split K to bf16 hi/lo in
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
         const float c0 = -lse2 * LN2_F;
         float m2 = NEG_INF_F;
         const bool plain = !p.prior && !p.soft;                              // uniform
-        if (col_ok && plain) {
+        if (col_ok && plain && !p.out16) {
             // the common case, kept free of loop-carried state: a uniform row base (scalar) plus one
             // 32-bit lane offset per store
             float *const out_b = p.logp + (size_t)b * p.Tx * p.Ty;
@@ -568,6 +575,29 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
                 }
             }
         }
+        if (col_ok && plain && p.out16) {
+            // the same with 2-byte stores (bf16 log-probs: half the write traffic)
+            __bf16 *const out_b = reinterpret_cast<__bf16 *>(p.logp) + (size_t)b * p.Tx * p.Ty;
+            const int lane_off32 = 4 * half * p.Ty + col;
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+                if (32 * r < p.Tx) {                                         // uniform
+                    if (32 * r + 32 <= p.Tx) {                               // uniform: a full tile
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                            out_b[(size_t)iu * p.Ty + lane_off32] = (__bf16)fmaf(lg[r][e], LN2_F, c0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                            if (i_lane + iu < p.Tx) out_b[(size_t)iu * p.Ty + lane_off32] = (__bf16)fmaf(lg[r][e], LN2_F, c0);
+                        }
+                    }
+                }
+            }
+        }
         if (col_ok && !plain) {
 #pragma unroll
             for (int r = 0; r < G; ++r) {
@@ -578,7 +608,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
                     float v = fmaf(lg[r][e], LN2_F, c0);
                     if (full || i_lane + iu < p.Tx) {
                         if (p.prior) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
-                        p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                        store_logp(p, lane_off + (size_t)iu * p.Ty, v);
                     }
                     lg[r][e] = v;
                     m2 = fmaxf(m2, v);
@@ -670,7 +700,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
                     float v = lg[e] - lse;
                     if (p.prior && ok) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
                     if (ok) {
-                        p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                        store_logp(p, lane_off + (size_t)iu * p.Ty, v);
                         if (p.soft) p.soft[lane_off + (size_t)iu * p.Ty] = __expf(v);   // no prior here (host checks)
                     }
                 }
@@ -817,7 +847,7 @@ __global__ __launch_bounds__(256) void softattn_exact_kernel(SoftAttnParams p, i
                     if (p.prior && ok) v += __logf(p.prior[lane_off + (size_t)iu * p.Ty] + 1e-8f);
                     if (pass == 0) {
                         if (ok) {
-                            p.logp[lane_off + (size_t)iu * p.Ty] = v;
+                            store_logp(p, lane_off + (size_t)iu * p.Ty, v);
                             if (p.soft && !p.prior) p.soft[lane_off + (size_t)iu * p.Ty] = __expf(v);
                         }
                         if (npass == 2 && ok && v != NEG_INF_F) {
@@ -1453,7 +1483,16 @@ size_t aligner_softattn_workspace_bytes(int B, int C, int Tx) {
 int aligner_softattn_f32(const float *keys, const float *queries, const int32_t *t_xs, const float *prior,
                          float *logp_out, float *soft_out, void *workspace, size_t workspace_bytes, int B, int C,
                          int Tx, int Ty, float temperature, int sim, void *stream) {
+    return aligner_softattn(keys, queries, t_xs, prior, logp_out, ALIGNER_DT_F32, soft_out, workspace, workspace_bytes, B,
+                            C, Tx, Ty, temperature, sim, stream);
+}
+
+int aligner_softattn(const float *keys, const float *queries, const int32_t *t_xs, const float *prior,
+                     void *logp_out, int logp_dtype, float *soft_out, void *workspace, size_t workspace_bytes, int B,
+                     int C, int Tx, int Ty, float temperature, int sim, void *stream) {
     if (!keys || !queries || !logp_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (logp_dtype != ALIGNER_DT_F32 && logp_dtype != ALIGNER_DT_BF16)
+        return fail(ALIGNER_EINVAL, "logp dtype %d not supported (F32 or BF16)", logp_dtype);
     if (B < 0 || C < 1 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d C=%d Tx=%d Ty=%d", B, C, Tx, Ty);
     if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
     if (C > 256) return fail(ALIGNER_EDOM, "C=%d exceeds 256 attention channels", C);
@@ -1462,10 +1501,10 @@ int aligner_softattn_f32(const float *keys, const float *queries, const int32_t 
     const SaLayout L = sa_layout(B, C, Tx);
     if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
-    SoftAttnParams p{keys, queries, t_xs, prior, logp_out, soft_out,
+    SoftAttnParams p{keys, queries, t_xs, prior, static_cast<float *>(logp_out), soft_out,
                      reinterpret_cast<const uint4 *>(ws + L.hi_off), reinterpret_cast<const uint4 *>(ws + L.lo_off),
                      reinterpret_cast<const float *>(ws + L.kn_off), L.RT, g_debug_stamps, B, C, Tx, Ty, temperature,
-                     sim};
+                     sim, logp_dtype == ALIGNER_DT_BF16 ? 1 : 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     // sharp temperatures multiply the bf16x3 product error past the 1e-4 bound: exact fp32 products instead
     // (rule and reasoning: softattn_exact_kernel)

@@ -109,12 +109,13 @@ def conv1d_raw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 
 def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optional[torch.Tensor] = None,
                    prior: Optional[torch.Tensor] = None, temperature: float = 0.0005, sim: str = "l2",
-                   want_soft: bool = False, out: Optional[torch.Tensor] = None
-                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                   want_soft: bool = False, out: Optional[torch.Tensor] = None,
+                   logp_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """logp[b,i,j] (and optionally softmax over text of it) from encoded text/mel.
 
     keys_enc [B,C,T_text], queries_enc [B,C,T_mel] fp32 (channel-major, as the conv
-    encoders emit).  Rows i >= t_x[b] are masked to -inf."""
+    encoders emit).  Rows i >= t_x[b] are masked to -inf.  logp_dtype torch.bfloat16 writes the log-probs as
+    bf16 (half the traffic; align() / maximum_path() read them as they are)."""
     _lib.require_gpu()
     k = _chk(keys_enc, "keys_enc"); q = _chk(queries_enc, "queries_enc")
     B, C, Tx = k.shape
@@ -128,15 +129,22 @@ def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optio
         prior = _chk(prior, "prior")
         if tuple(prior.shape) != (B, Tx, Ty):
             raise ValueError("prior must be [B,T_text,T_mel]")
-    logp = out if out is not None else torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev)
+    if out is not None:
+        logp_dtype = out.dtype
+    if logp_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("logp_dtype must be torch.float32 or torch.bfloat16")
+    logp = out if out is not None else torch.empty((B, Tx, Ty), dtype=logp_dtype, device=dev)
+    if tuple(logp.shape) != (B, Tx, Ty) or not logp.is_contiguous():
+        raise ValueError("out must be a contiguous [B,T_text,T_mel] tensor")
     soft = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_soft else None
     simc = {"l2": _lib.SIM_L2, "dot": _lib.SIM_DOT}[sim]
     lib = _lib.load()
     with torch.cuda.device(dev):
         ws = _workspace(dev, lib.aligner_softattn_workspace_bytes(B, C, Tx))
-        _lib.check(lib.aligner_softattn_f32(
+        _lib.check(lib.aligner_softattn(
             k.data_ptr(), q.data_ptr(), None if t_x is None else t_x.data_ptr(),
             None if prior is None else prior.data_ptr(), logp.data_ptr(),
+            _lib.DT_BF16 if logp_dtype == torch.bfloat16 else _lib.DT_F32,
             None if soft is None else soft.data_ptr(), ws.data_ptr(), ws.numel(),
             B, C, Tx, Ty, float(temperature), simc, _stream(dev)))
     return logp, soft

@@ -197,6 +197,14 @@ int aligner_maxpath_host_f32(int32_t *paths, const float *values,
  * temperatures take an exact-product kernel (fp32 MFMA, about a quarter of the matrix rate) automatically.
  */
 size_t aligner_softattn_workspace_bytes(int B, int C, int Tx);
+/* logp_out_dev of logp_dtype F32 or BF16 (round to nearest even; the layout aligner_maxpath reads directly:
+ * BASELINE config 5, "bf16 similarity + int32 path"); everything else as aligner_softattn_f32. */
+int aligner_softattn(const float *keys_dev, const float *queries_dev,
+                     const int32_t *t_xs_dev, const float *prior_dev,
+                     void *logp_out_dev, int logp_dtype, float *soft_out_dev,
+                     void *workspace_dev, size_t workspace_bytes,
+                     int B, int C, int Tx, int Ty,
+                     float temperature, int sim, void *stream);
 int aligner_softattn_f32(const float *keys_dev, const float *queries_dev,
                          const int32_t *t_xs_dev, const float *prior_dev,
                          float *logp_out_dev, float *soft_out_dev,

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(built_lib):
 
 
 def test_abi_version_and_errors(built_lib):
-    assert built_lib.aligner_abi_version() == 1
+    assert built_lib.aligner_abi_version() == 2
     assert built_lib.aligner_maxpath_workspace_bytes(64, 200, 1000) > 64 * 32 * 256 * 4
     assert built_lib.aligner_maxpath_workspace_bytes(1, 0, 5) == 0
     # argument validation happens before any HIP call
@@ -100,14 +100,15 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
-def test_generated_sweep_asm_is_in_sync(tmp_path):
-    """aligner_amd/csrc/maxpath_sweep_asm.inc is generated (tools/gen_sweep_asm.py) and committed: the
+@pytest.mark.parametrize("name", ["gen_sweep_asm", "gen_walk_asm"])
+def test_generated_asm_is_in_sync(tmp_path, name):
+    """aligner_amd/csrc/maxpath_{sweep,walk}_asm.inc are generated (tools/gen_*_asm.py) and committed: the
     committed text must be what the generator writes."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("gen_sweep_asm", os.path.join(ROOT, "tools", "gen_sweep_asm.py"))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     committed = open(gen.OUT).read()
-    gen.OUT = str(tmp_path / "maxpath_sweep_asm.inc")
+    gen.OUT = str(tmp_path / "generated.inc")
     gen.main()
     assert open(gen.OUT).read() == committed

@@ -182,6 +182,39 @@ def test_pipeline_similarity_then_dp(dev):
     assert np.array_equal(res.path.cpu().numpy(), want)
 
 
+def test_bf16_log_probs_and_long_form_pipeline(dev):
+    """bf16 log-prob output (round to nearest even of the fp32 result, bit for bit) on all three kernel forms,
+    and BASELINE config C5's data path at its full size [8, T_text=500, T_mel=4000]: bf16 similarity straight
+    into the DP (no conversion pass), int32 path equal to the oracle DP on the same bf16 log-probs."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from oracle import maxpath_oracle as O
+    g = torch.Generator().manual_seed(55)
+    for (B, C, Tx, Ty, exact) in [(3, 80, 200, 520, False), (2, 80, 300, 264, False), (2, 80, 70, 200, True)]:
+        k, q = torch.randn(B, C, Tx, generator=g).to(dev), torch.randn(B, C, Ty, generator=g).to(dev)
+        t_x = torch.tensor([Tx] + [Tx // 2] * (B - 1), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().aligner_debug_set_option(b"softattn_exact", int(exact)))
+        try:
+            f32, _ = aligner_amd.soft_attention(k, q, t_x=t_x)
+            b16, _ = aligner_amd.soft_attention(k, q, t_x=t_x, logp_dtype=torch.bfloat16)
+        finally:
+            _lib.load().aligner_debug_set_option(b"softattn_exact", 0)
+        torch.cuda.synchronize()
+        assert b16.dtype == torch.bfloat16 and torch.equal(b16.cpu(), f32.bfloat16().cpu()), (B, C, Tx, Ty)
+    B, C, Tx, Ty = 8, 80, 500, 4000
+    k, q = torch.randn(B, C, Tx, generator=g).to(dev), torch.randn(B, C, Ty, generator=g).to(dev)
+    t_x = torch.tensor([500, 480, 333, 250, 500, 77, 412, 499], dtype=torch.int32)
+    t_y = torch.tensor([4000, 3999, 2800, 2100, 3504, 700, 3333, 4000], dtype=torch.int32)
+    logp, _ = aligner_amd.soft_attention(k, q, t_x=t_x.to(dev), logp_dtype=torch.bfloat16)
+    res = aligner_amd.align(logp, t_x.to(dev), t_y.to(dev), path_dtype=torch.int32)
+    torch.cuda.synchronize()
+    v = logp.float().cpu().numpy().copy()
+    want = np.zeros(v.shape, np.int32)
+    O.maximum_path_c(want, v, t_x.numpy().copy(), t_y.numpy().copy())
+    assert np.array_equal(res.path.cpu().numpy(), want)
+    assert np.array_equal(res.durations.cpu().numpy().sum(1), t_y.numpy())
+
+
 @pytest.mark.parametrize("B", [6, 64])
 def test_c3_shape_full_pipeline(dev, B):
     """BASELINE config C3: conv text/mel encoders -> log-probs -> DP on an LJSpeech-shaped batch
