@@ -1,0 +1,76 @@
+"""MoBoAligner monotonic boundary search on the HIP path (BASELINE config 5).
+
+Build-defined spec -- the reference snapshot only names the branch and links the paper (README.md:9-13,49):
+boundaries 0 = b_-1 < b_0 < ... < b_{t_x-1} = t_y, token durations 1..max_duration,
+P(b_i = j | b_{i-1} = k) = softmax over the feasible j in (k, k + max_duration] of energies[b, i, j-1].
+All arithmetic runs in libaligner_amd.so (csrc/mobo.hip); torch only owns the buffers.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DT_F32, torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}
+_workspaces = _lib.StreamWorkspaces(zero=True)
+
+
+class BoundarySearch(NamedTuple):
+    boundaries: torch.Tensor              # [B,Tx] int32: end boundary b_i of every token (MAP sequence)
+    durations: torch.Tensor               # [B,Tx] int32
+    map_score: torch.Tensor               # [B] fp32: log-probability of that sequence
+    log_alpha: Optional[torch.Tensor]     # [B,Tx,Ty] fp32: log P(b_i = j) at [i, j-1]
+    gamma: Optional[torch.Tensor]         # [B,Tx,Ty] fp32: soft alignment P(b_{i-1} <= y < b_i)
+
+
+def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int,
+                    want_log_alpha: bool = False, want_gamma: bool = False) -> BoundarySearch:
+    """energies [B,T_text,T_mel] (fp32 / bf16 / fp16, GPU), lengths [B].  Asynchronous on the current stream."""
+    _lib.require_gpu()
+    if energies.dim() != 3 or not energies.is_cuda:
+        raise ValueError("energies must be a GPU tensor [B, T_text, T_mel]")
+    e = energies.detach()
+    if e.dtype not in _DT:
+        e = e.float()
+    e = e.contiguous()
+    B, Tx, Ty = e.shape
+    dev = e.device
+    tx = torch.as_tensor(t_x).detach().to(device=dev, dtype=torch.int32).contiguous()
+    ty = torch.as_tensor(t_y).detach().to(device=dev, dtype=torch.int32).contiguous()
+    if tx.shape != (B,) or ty.shape != (B,):
+        raise ValueError("t_x / t_y must have one entry per utterance")
+    want_log_alpha = want_log_alpha or want_gamma
+    bnd = torch.empty((B, Tx), dtype=torch.int32, device=dev)
+    dur = torch.empty((B, Tx), dtype=torch.int32, device=dev)
+    score = torch.empty((B,), dtype=torch.float32, device=dev)
+    la = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_log_alpha else None
+    ga = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_gamma else None
+    lib = _lib.load()
+    if B > 0:
+        with torch.cuda.device(dev):
+            ws = _workspaces.get(dev, lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty))
+            _lib.check(lib.aligner_boundary_search(
+                e.data_ptr(), _DT[e.dtype], tx.data_ptr(), ty.data_ptr(), int(max_duration), bnd.data_ptr(),
+                dur.data_ptr(), score.data_ptr(), None if la is None else la.data_ptr(),
+                None if ga is None else ga.data_ptr(), ws.data_ptr(), ws.numel(), B, Tx, Ty,
+                torch.cuda.current_stream(dev).cuda_stream))
+    return BoundarySearch(bnd, dur, score, la, ga)
+
+
+def read_status(device=None) -> int:
+    """ALIGNER_ST_* bits left by boundary_search() calls on `device` since the last read (blocking)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    st = 0
+    out = np.zeros(1, np.int32)
+    with torch.cuda.device(device):
+        torch.cuda.synchronize(device)
+        for ws in _workspaces.on_device(device):
+            _lib.check(_lib.load().aligner_maxpath_read_status(ws.data_ptr(), out.ctypes.data,
+                                                               torch.cuda.current_stream(device).cuda_stream))
+            st |= int(out[0])
+    return st

@@ -260,6 +260,30 @@ int aligner_beta_binomial_prior_f32(const int32_t *t_xs_dev, const int32_t *t_ys
 int aligner_regulate_f32(const float *h_dev, const int32_t *durations_dev, float *out_dev, int32_t *tok_out_dev,
                          int B, int C, int Tx, int Ty, void *stream);
 
+/*
+ * MoBoAligner monotonic boundary search (BASELINE config 5; build-defined spec from the paper the reference
+ * links at README.md:49 -- its code is on a branch that is not in the snapshot; stated in full in
+ * oracle/mobo_oracle.py and aligner_amd/csrc/mobo.hip).  Boundaries 0 = b_-1 < b_0 < ... < b_{t_x-1} = t_y,
+ * token durations 1..max_duration, P(b_i = j | b_{i-1} = k) = softmax over the feasible j in (k, k+max_duration]
+ * of energies[b,i,j-1].
+ *   energies_dev   [B,Tx,Ty] of energy_dtype F32, BF16 or F16 (the alignment layout, mel axis contiguous)
+ *   boundaries_out_dev [B,Tx] int32: b_i of the most probable boundary sequence (rows >= t_x: t_y)
+ *   durations_out_dev  optional [B,Tx] int32; map_score_out_dev optional [B] fp32 (its log-probability)
+ *   log_alpha_out_dev  optional [B,Tx,Ty] fp32: log P(b_i = j) at [i, j-1], -inf where impossible
+ *   gamma_out_dev      optional [B,Tx,Ty] fp32 soft alignment P(b_{i-1} <= y < b_i); needs log_alpha_out_dev
+ *   workspace_dev      aligner_boundary_search_workspace_bytes(B,Tx,Ty) bytes, first 256 zeroed once (status word
+ *                      as for aligner_maxpath: ALIGNER_ST_BAD_LENGTHS for an utterance without any segmentation,
+ *                      i.e. not t_x <= t_y <= t_x*max_duration; its outputs are 0 / -inf)
+ * Ty is limited by LDS (about 4400 positions at max_duration 32); ALIGNER_EDOM beyond.
+ */
+size_t aligner_boundary_search_workspace_bytes(int B, int Tx, int Ty);
+int aligner_boundary_search(const void *energies_dev, int energy_dtype,
+                            const int32_t *t_xs_dev, const int32_t *t_ys_dev, int max_duration,
+                            int32_t *boundaries_out_dev, int32_t *durations_out_dev, float *map_score_out_dev,
+                            float *log_alpha_out_dev, float *gamma_out_dev,
+                            void *workspace_dev, size_t workspace_bytes,
+                            int B, int Tx, int Ty, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

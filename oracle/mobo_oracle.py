@@ -1,0 +1,159 @@
+"""oracle/mobo_oracle.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU float64 restatement of the MoBoAligner monotonic boundary search (BASELINE config 5,
+SURVEY.md section 8 rows a7 / f3).
+
+PARITY UNPINNED: the MoBoAligner code is on another git branch of the reference and is not in the
+snapshot -- /root/reference/README.md:9-13 only names the branch, README.md:49 links the paper
+(Li et al., "MoBoAligner: a Neural Alignment Model for Non-autoregressive TTS with Monotonic Boundary
+Search", Interspeech 2020).  This file restates the paper's boundary formulation as this build reads
+it, with the maximum-duration window the reference's README names as that branch's limitation
+(README.md:13); every constant and convention below is this build's choice, and the HIP path is
+checked against THIS file, which in turn is pinned only to brute-force enumeration of all boundary
+sequences on tiny shapes (tests/test_mobo.py).  Only tests/, __graft_entry__.smoke() and bench.py
+may import it.
+
+Model.  Tokens i = 0..I-1, frames y = 0..J-1, energies e[i, y] (any real numbers; the similarity /
+log-likelihood matrix in the alignment layout [T_text, T_mel]).  A segmentation is a boundary
+sequence 0 = b_{-1} < b_0 < ... < b_{I-1} = J: token i owns frames [b_{i-1}, b_i), its duration
+d_i = b_i - b_{i-1} is between 1 and D (the maximum-duration window).  Boundaries are searched left
+to right; given the previous boundary k, the right boundary of token i is drawn among the feasible
+positions with probability proportional to the exponentiated energy of the token at its LAST frame:
+
+    P(b_i = j | b_{i-1} = k) = exp(e[i, j-1]) / sum_{m in A_i(k)} exp(e[i, m-1])
+    A_i(k) = { m : k < m <= k + D,  lo_i <= m <= hi_i }
+    hi_i = J - (I-1-i)                  (every later token keeps at least one frame)
+    lo_i = max(i+1, J - (I-1-i)*D)      (the later tokens can still reach J)
+
+so every row of the chain is a proper distribution and every sequence with positive probability
+ends at b_{I-1} = J.  Quantities (all in natural-log units):
+
+    log_alpha[i, j-1] = log P(b_i = j)                                    forward variable
+    gamma[i, y]       = P(b_{i-1} <= y < b_i) = cdf_{i-1}(y) - cdf_i(y)   soft alignment, columns sum to 1
+    boundaries[i]     = b_i of the MAP sequence (max-product search; ties: the shortest token,
+                        i.e. the LARGEST previous boundary), durations = differences
+    map_score         = log-probability of that sequence
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+NEG = -np.inf
+
+
+def _bounds(I: int, J: int, D: int, i: int):
+    hi = J - (I - 1 - i)
+    lo = max(i + 1, J - (I - 1 - i) * D)
+    return lo, hi
+
+
+def feasible(I: int, J: int, D: int) -> bool:
+    return 1 <= I <= J <= I * D
+
+
+def _logsumexp(a):
+    a = np.asarray(a, np.float64)
+    m = a.max() if a.size else NEG
+    if not np.isfinite(m):
+        return m
+    return m + np.log(np.exp(a - m).sum())
+
+
+def boundary_search(e: np.ndarray, D: int):
+    """e [I, J] float -> dict(log_alpha [I,J], gamma [I,J], boundaries [I], durations [I], map_score).
+
+    Plain loops over tokens and previous boundaries; keep sizes small (I*J*D <= ~1e7)."""
+    e = np.asarray(e, np.float64)
+    I, J = e.shape
+    if not feasible(I, J, D):
+        raise ValueError(f"infeasible: need I <= J <= I*D (I={I}, J={J}, D={D})")
+    la_prev = np.full(J + 1, NEG)           # log P(b_{i-1} = k), k = 0..J
+    la_prev[0] = 0.0
+    de_prev = la_prev.copy()                # max-product twin
+    log_alpha = np.full((I, J), NEG)
+    back = np.zeros((I, J + 1), np.int64)
+    cdf_prev = np.ones(J)                   # P(b_{-1} <= y) = 1
+    gamma = np.zeros((I, J))
+    for i in range(I):
+        lo, hi = _bounds(I, J, D, i)
+        s = np.full(J + 1, NEG)
+        s[1:] = e[i]                        # s[j] = e[i, j-1]: energy at the last frame of a token ending at j
+        # normaliser per previous boundary k
+        L = np.full(J + 1, NEG)
+        for k in range(J):
+            a, b = max(k + 1, lo), min(k + D, hi)
+            if a <= b and (np.isfinite(la_prev[k]) or np.isfinite(de_prev[k])):
+                L[k] = _logsumexp(s[a:b + 1])
+        la = np.full(J + 1, NEG)
+        de = np.full(J + 1, NEG)
+        for j in range(lo, hi + 1):
+            ks = np.arange(max(0, j - D), j)
+            ok = np.isfinite(L[ks])
+            if not ok.any():
+                continue
+            with np.errstate(invalid="ignore"):
+                u = np.where(ok, la_prev[ks] - L[ks], NEG)
+                v = np.where(ok, de_prev[ks] - L[ks], NEG)
+            la[j] = s[j] + _logsumexp(u)
+            vm = v.max()
+            if np.isfinite(vm):
+                kbest = ks[np.nonzero(v == vm)[0].max()]           # ties: the largest previous boundary
+                de[j] = s[j] + vm
+                back[i, j] = kbest
+        log_alpha[i] = la[1:]
+        cdf = np.cumsum(np.exp(la[1:]))                            # P(b_i <= y + 1)... index y: b_i <= y+1
+        # gamma[i, y] = P(b_{i-1} <= y) - P(b_i <= y)
+        cdf_i = np.concatenate([[0.0], cdf[:-1]])                  # P(b_i <= y), y = 0..J-1
+        gamma[i] = cdf_prev - cdf_i
+        cdf_prev = cdf_i
+        la_prev, de_prev = la, de
+    bnd = np.zeros(I, np.int64)
+    j = J
+    for i in range(I - 1, -1, -1):
+        bnd[i] = j
+        j = back[i, j]
+    dur = np.diff(np.concatenate([[0], bnd]))
+    return dict(log_alpha=log_alpha, gamma=gamma, boundaries=bnd.astype(np.int32),
+                durations=dur.astype(np.int32), map_score=float(de_prev[J]))
+
+
+def sequence_log_prob(e: np.ndarray, D: int, boundaries) -> float:
+    """log-probability of one boundary sequence under the chain (-inf if it violates a constraint)."""
+    e = np.asarray(e, np.float64)
+    I, J = e.shape
+    k, lp = 0, 0.0
+    for i in range(I):
+        j = int(boundaries[i])
+        lo, hi = _bounds(I, J, D, i)
+        a, b = max(k + 1, lo), min(k + D, hi)
+        if not (a <= j <= b):
+            return NEG
+        lp += e[i, j - 1] - _logsumexp(e[i, a - 1:b])
+        k = j
+    return lp if k == J else NEG
+
+
+def brute_force(e: np.ndarray, D: int):
+    """Enumerate every boundary sequence (tiny shapes only): the pin of boundary_search."""
+    e = np.asarray(e, np.float64)
+    I, J = e.shape
+    log_alpha = np.full((I, J), NEG)
+    gamma = np.zeros((I, J))
+    best, best_b = NEG, None
+    for durs in itertools.product(range(1, D + 1), repeat=I):
+        if sum(durs) != J:
+            continue
+        b = np.cumsum(durs)
+        lp = sequence_log_prob(e, D, b)
+        if not np.isfinite(lp):
+            continue
+        for i in range(I):
+            log_alpha[i, b[i] - 1] = np.logaddexp(log_alpha[i, b[i] - 1], lp)
+            gamma[i, (b[i - 1] if i else 0):b[i]] += np.exp(lp)
+        # ties: prefer the lexicographically larger boundary sequence seen from the LAST token backwards,
+        # which is what "largest previous boundary first" in the backtrack produces
+        if lp > best or (lp == best and tuple(b[::-1]) > tuple(best_b[::-1])):
+            best, best_b = lp, b
+    return dict(log_alpha=log_alpha, gamma=gamma, boundaries=np.asarray(best_b, np.int32), map_score=float(best))

@@ -1,0 +1,131 @@
+"""MoBoAligner monotonic boundary search (BASELINE config 5).
+
+Parity UNPINNED (the reference snapshot holds only the branch name and the paper link, README.md:9-13,49):
+the float64 oracle oracle/mobo_oracle.py is this build's restatement of the paper's formulation, pinned here to
+brute-force enumeration of every boundary sequence on tiny shapes; the HIP path is checked against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mobo_oracle as M
+
+gpu = pytest.mark.gpu
+
+
+def test_oracle_matches_brute_force_enumeration():
+    rng = np.random.default_rng(3)
+    n = 0
+    for (I, J, D) in [(1, 1, 1), (1, 3, 3), (2, 3, 2), (3, 5, 3), (3, 7, 3), (4, 6, 2), (4, 9, 4), (5, 8, 3), (3, 9, 3),
+                      (2, 8, 7), (6, 6, 3)]:
+        for rep in range(3):
+            e = rng.standard_normal((I, J)) * (1.0 + 2.0 * rep)
+            got, want = M.boundary_search(e, D), M.brute_force(e, D)
+            fin = np.isfinite(want["log_alpha"])
+            assert np.array_equal(np.isfinite(got["log_alpha"]), fin)
+            assert np.allclose(got["log_alpha"][fin], want["log_alpha"][fin], atol=1e-10)
+            assert np.allclose(got["gamma"], want["gamma"], atol=1e-10)
+            assert np.array_equal(got["boundaries"], want["boundaries"])
+            assert abs(got["map_score"] - want["map_score"]) < 1e-10
+            assert abs(M.sequence_log_prob(e, D, got["boundaries"]) - got["map_score"]) < 1e-10
+            n += 1
+    assert n == 33
+
+
+def test_oracle_properties_at_moderate_size():
+    rng = np.random.default_rng(4)
+    I, J, D = 40, 300, 16
+    r = M.boundary_search(rng.standard_normal((I, J)) * 2, D)
+    assert np.allclose(np.exp(r["log_alpha"]).sum(1), 1.0, atol=1e-9)        # every boundary is somewhere
+    assert np.allclose(r["gamma"].sum(0), 1.0, atol=1e-9)                    # every frame belongs to one token
+    assert r["gamma"].min() > -1e-12
+    d = r["durations"]
+    assert d.sum() == J and d.min() >= 1 and d.max() <= D and r["boundaries"][-1] == J
+    with pytest.raises(ValueError):
+        M.boundary_search(np.zeros((3, 10)), 3)                              # 3 tokens of <= 3 frames cannot cover 10
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _check_against_oracle(dev, e, tx, ty, D, dt=torch.float32):
+    import aligner_amd
+    ed = torch.from_numpy(e).to(dt)
+    r = aligner_amd.boundary_search(ed.to(dev), torch.from_numpy(tx), torch.from_numpy(ty), D, want_log_alpha=True,
+                                    want_gamma=True)
+    torch.cuda.synchronize()
+    la, ga = r.log_alpha.cpu().numpy().astype(np.float64), r.gamma.cpu().numpy().astype(np.float64)
+    bnd, dur, sc = r.boundaries.cpu().numpy(), r.durations.cpu().numpy(), r.map_score.cpu().numpy()
+    e64 = ed.float().numpy().astype(np.float64)
+    for b in range(e.shape[0]):
+        I, J = int(tx[b]), int(ty[b])
+        want = M.boundary_search(e64[b, :I, :J], D)
+        fin = np.isfinite(want["log_alpha"])
+        assert np.array_equal(np.isfinite(la[b, :I, :J]), fin), b
+        assert np.all(np.isneginf(la[b, I:])) and np.all(np.isneginf(la[b, :I, J:]))
+        # fp32 log-domain recursion over I rows: absolute error grows with the depth of the chain
+        assert np.abs(la[b, :I, :J][fin] - want["log_alpha"][fin]).max() < 2e-3 + 2e-5 * I, b
+        assert np.abs(ga[b, :I, :J] - want["gamma"]).max() < 2e-4 + 2e-6 * I, b
+        assert np.all(ga[b, I:] == 0) and np.all(ga[b, :, J:] == 0)
+        # the MAP sequence: a valid segmentation whose log-probability (evaluated in float64) is the optimum
+        bb = bnd[b, :I]
+        assert np.array_equal(np.diff(np.concatenate([[0], bb])), dur[b, :I]) and bb[-1] == J
+        assert dur[b, :I].min() >= 1 and dur[b, :I].max() <= D and np.all(bnd[b, I:] == J)
+        lp = M.sequence_log_prob(e64[b, :I, :J], D, bb)
+        assert lp >= want["map_score"] - 1e-3 - 1e-5 * I, (b, lp, want["map_score"])
+        assert abs(sc[b] - lp) < 2e-3 + 2e-5 * I
+
+
+@gpu
+@pytest.mark.parametrize("B,Tx,Ty,D", [(3, 1, 1, 1), (2, 5, 9, 3), (4, 12, 40, 8), (3, 40, 300, 16), (2, 64, 257, 32),
+                                       (2, 30, 1100, 64), (1, 100, 600, 7), (2, 9, 90, 10)])
+def test_boundary_search_matches_oracle(dev, B, Tx, Ty, D):
+    rng = np.random.default_rng(B * 100 + Tx)
+    e = (rng.standard_normal((B, Tx, Ty)) * 2).astype(np.float32)
+    tx = np.array([Tx] + [int(rng.integers(max(1, -(-Ty // (2 * D))), Tx + 1)) for _ in range(B - 1)], np.int32)
+    ty = np.array([Ty] + [int(rng.integers(tx[b], min(Ty, tx[b] * D) + 1)) for b in range(1, B)], np.int32)
+    if Ty > Tx * D:
+        ty[0] = Tx * D
+    _check_against_oracle(dev, e, tx, ty, D)
+
+
+@gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_boundary_search_sixteen_bit_energies(dev, dt):
+    rng = np.random.default_rng(8)
+    e = (rng.standard_normal((2, 20, 150)) * 2).astype(np.float32)
+    _check_against_oracle(dev, e, np.array([20, 13], np.int32), np.array([150, 90], np.int32), 16, dt)
+
+
+@gpu
+def test_boundary_search_infeasible_and_properties_at_config5_size(dev):
+    """BASELINE config 5 at full size [8, T_text=500, T_mel=4000], bf16 scores in, int32 boundaries out: properties
+    that need no oracle (every row of alpha and every column of gamma sums to 1, durations within the window),
+    one utterance checked against the oracle on a slice it can afford, and the infeasible case."""
+    import aligner_amd
+    from aligner_amd import mobo
+    g = torch.Generator().manual_seed(12)
+    B, Tx, Ty, D = 8, 500, 4000, 32
+    e = (torch.randn(B, Tx, Ty, generator=g) * 2).bfloat16()
+    tx = torch.tensor([500, 480, 333, 250, 500, 125, 412, 499], dtype=torch.int32)
+    ty = torch.tensor([4000, 3999, 2800, 2100, 3504, 4000, 3333, 4000], dtype=torch.int32)
+    r = aligner_amd.boundary_search(e.to(dev), tx, ty, D, want_gamma=True)
+    torch.cuda.synchronize()
+    la, ga, dur, bnd = r.log_alpha.cpu(), r.gamma.cpu(), r.durations.cpu().numpy(), r.boundaries.cpu().numpy()
+    for b in range(B):
+        I, J = int(tx[b]), int(ty[b])
+        assert torch.allclose(torch.exp(la[b, :I, :J].double()).sum(1), torch.ones(I, dtype=torch.float64), atol=2e-2)
+        assert torch.allclose(ga[b, :I, :J].sum(0), torch.ones(J), atol=2e-2)
+        assert float(ga[b].min()) > -1e-3
+        assert dur[b, :I].sum() == J and dur[b, :I].min() >= 1 and dur[b, :I].max() <= D and bnd[b, I - 1] == J
+    assert mobo.read_status(dev) == 0
+    # a small one against the oracle with the same window, and an utterance no segmentation can cover
+    _check_against_oracle(dev, e[5:6, :60, :480].float().numpy(), np.array([60], np.int32), np.array([480], np.int32), D,
+                          torch.bfloat16)
+    r = aligner_amd.boundary_search(e[:2, :10, :400].to(dev), torch.tensor([10, 10]), torch.tensor([400, 300]), 32)
+    torch.cuda.synchronize()
+    assert mobo.read_status(dev) & 1
+    assert r.durations[0].sum().item() == 0 and r.durations[1].sum().item() == 300
