@@ -16,11 +16,11 @@
 //     la_i(j)     = e_i(j) + logsumexp_{k in [j-D, j)} (la_{i-1}(k) - L_i(k))
 //     delta_i(j)  = e_i(j) +    max    _{k in [j-D, j)} (delta_{i-1}(k) - L_i(k))   (+ argmax)
 // and a width-D window over blocks of D aligned positions is (a suffix of one block) + (a prefix of the next):
-// two lookups into per-block prefix / suffix scans instead of D terms.  The scans are kept as log values with
-// their own running maxima and the two parts of a window are only ever ADDED, so a window keeps fp32 relative
-// precision however far below the row's bulk it lies (a row-wide prefix sum would cancel there, a block
-// normalised by one maximum underflows).  The scans run one block per thread (D serial steps, J/D threads busy); everything else runs
-// one position per lane.  All logs are base 2 inside (v_exp_f32 / v_log_f32 are exp2 / log2), "log 0" is the
+// two lookups into per-block prefix / suffix sums instead of D terms.  The sums are fp64 (2^(v - block max), a
+// chain of plain adds) and the two parts of a window are only ever ADDED, so a window keeps full relative
+// precision however far below the row's bulk it lies (a row-wide prefix sum would cancel there, fp32 sums
+// normalised by one block maximum underflow).  The exp2s run one position per lane; only the adds of a block's
+// scan are serial (one block per thread, J/D threads busy).  All logs are base 2 inside (v_exp_f32 / v_log_f32 are exp2 / log2), "log 0" is the
 // finite -1e30, which absorbs every addend: no inf - inf.
 #include <hip/hip_runtime.h>
 
@@ -48,59 +48,87 @@ struct MoboParams {
     int B, Tx, Ty, D, P;      // P = padded positions (multiple of D, >= Ty+1)
 };
 
-__device__ __forceinline__ float mb_load(const void *base, int vt, size_t idx) {
-    if (vt == 0) return static_cast<const float *>(base)[idx];
-    const unsigned h = static_cast<const unsigned short *>(base)[idx];
-    if (vt == 1) return __builtin_bit_cast(float, h << 16);
-    return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+// raw bits of one energy (the load), and their value (the conversion): kept apart so that the loads of the next
+// row can be in flight, unconverted, while this row is computed
+template <int VT> __device__ __forceinline__ unsigned mb_load_raw(const void *base, size_t idx) {
+    if (VT == 0) return static_cast<const unsigned *>(base)[idx];
+    return static_cast<const unsigned short *>(base)[idx];
 }
-
-// log2(2^x1 + 2^x2) with "log 0" = MB_NEG
-__device__ __forceinline__ float mb_lse2(float x1, float x2) {
-    const float m = fmaxf(x1, x2);
-    if (m <= 0.5f * MB_NEG) return MB_NEG;
-    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(x1 - m) + __builtin_amdgcn_exp2f(x2 - m));
+template <int VT> __device__ __forceinline__ float mb_value(unsigned raw) {
+    if (VT == 0) return __builtin_bit_cast(float, raw);
+    if (VT == 1) return __builtin_bit_cast(float, raw << 16);
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
 }
 
 // Position arrays in LDS carry one pad word per block of D (index = block * (D+1) + offset): the scan threads
 // walk their blocks in step, D words apart -- without the pad every lane of a wave would hit the same bank.
 //
-// One block per thread: log2-sum-exp2 of every prefix and of every suffix of the block, as LOG values.  Each
-// scan carries its own running maximum (s = sum of 2^(x - m), rescaled when m moves), so a prefix or suffix
-// that lies hundreds of bits below the block's largest entry keeps full relative precision -- a window far
-// from the row's bulk is made of exactly such parts (normalising a whole block by one maximum underflows there).
-__device__ __forceinline__ void mb_scan_lse(const float *x, float *pre, float *suf, int nblk, int D) {
+// Block scans in three steps, so that the only serial part is a chain of fp64 adds:
+//   mb_block_max   one block per thread: M[blk] = max of the block                       (D reads)
+//   mb_block_pow   one position per lane: T[x] = 2^(v - M[blk]) as a DOUBLE              (the exp2s, all parallel)
+//   mb_block_sums  one block per thread: S[x] = suffix sums of T, then T[x] = prefix sums (in place)
+// A double keeps 2^-1000: a prefix or suffix that lies hundreds of bits below the block's largest entry -- a
+// window far from the row's bulk is made of exactly such parts -- still has full relative precision (fp32 sums
+// normalised by one block maximum underflow there; measured, tests/test_mobo.py rows 57+ of the [64,257] case).
+__device__ __forceinline__ void mb_block_max(const float *__restrict__ x, float *__restrict__ bmax, int nblk, int D) {
     for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
         const int o = blk * (D + 1);
-        float m = MB_NEG, acc = 0.f;
-        for (int r = 0; r < D; ++r) {
-            const float v = x[o + r];
-            if (v > 0.5f * MB_NEG) {
-                if (v > m) { acc = acc * __builtin_amdgcn_exp2f(m - v) + 1.f; m = v; }
-                else       acc += __builtin_amdgcn_exp2f(v - m);
-            }
-            pre[o + r] = (m > 0.5f * MB_NEG) ? m + __builtin_amdgcn_logf(acc) : MB_NEG;
-        }
-        m = MB_NEG; acc = 0.f;
-        for (int r = D - 1; r >= 0; --r) {
-            const float v = x[o + r];
-            if (v > 0.5f * MB_NEG) {
-                if (v > m) { acc = acc * __builtin_amdgcn_exp2f(m - v) + 1.f; m = v; }
-                else       acc += __builtin_amdgcn_exp2f(v - m);
-            }
-            suf[o + r] = (m > 0.5f * MB_NEG) ? m + __builtin_amdgcn_logf(acc) : MB_NEG;
-        }
+        float M = MB_NEG;
+#pragma unroll 8
+        for (int r = 0; r < D; ++r) M = fmaxf(M, x[o + r]);       // (unrolled: the LDS reads of a batch go out together)
+        bmax[blk] = (M > 0.5f * MB_NEG) ? ceilf(M) : MB_NEG;      // an INTEGER reference: two blocks' sums are brought
+                                                                  // to a common scale by an exact ldexp (mb_window)
     }
+}
+__device__ __forceinline__ double mb_pow2(float f) {            // 2^f for f <= 0 as a double (0 below 2^-1000)
+    if (!(f > -1000.f)) return 0.0;
+    const float k = floorf(f);
+    return __builtin_ldexp((double)__builtin_amdgcn_exp2f(f - k), (int)k);
+}
+__device__ __forceinline__ float mb_log2(double s) {              // log2 of a double (MB_NEG for 0)
+    if (!(s > 0.0)) return MB_NEG;
+    int ex;
+    const double mant = __builtin_frexp(s, &ex);
+    return (float)ex + __builtin_amdgcn_logf((float)mant);
+}
+__device__ __forceinline__ void mb_block_sums(double *__restrict__ T, double *__restrict__ S, int nblk, int D) {
+    for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+        const int o = blk * (D + 1);
+        double acc = 0.0;
+#pragma unroll 8
+        for (int r = D - 1; r >= 0; --r) { acc += T[o + r]; S[o + r] = acc; }
+        acc = 0.0;
+        int r = 0;
+        for (; r + 8 <= D; r += 8) {               // in place: read a batch, then write it
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = T[o + r + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc += t[u]; T[o + r + u] = acc; }
+        }
+        for (; r < D; ++r) { acc += T[o + r]; T[o + r] = acc; }
+    }
+}
+// log2(2^M1 * S1 + 2^M2 * S2): the two parts of a window, each relative to its block's (integer) reference
+__device__ __forceinline__ float mb_window(float M1, double S1, float M2, double S2) {
+    const bool a = S1 > 0.0, b = S2 > 0.0;
+    if (!a && !b) return MB_NEG;
+    const float m = fmaxf(a ? M1 : MB_NEG, b ? M2 : MB_NEG);
+    const float d1 = a ? fmaxf(M1 - m, -2000.f) : 0.f, d2 = b ? fmaxf(M2 - m, -2000.f) : 0.f;   // integers <= 0
+    const double t = (a ? __builtin_ldexp(S1, (int)d1) : 0.0) + (b ? __builtin_ldexp(S2, (int)d2) : 0.0);
+    return m + mb_log2(t);
 }
 
 // One block per thread: position of the maximum of every prefix (ties: the LARGEST position) and of every
 // suffix (ties: the largest position as well), as offsets inside the block.
-__device__ __forceinline__ void mb_scan_argmax(const float *x, unsigned short *ipre, unsigned short *isuf, int nblk, int D) {
+__device__ __forceinline__ void mb_scan_argmax(const float *__restrict__ x, unsigned short *__restrict__ ipre,
+                                               unsigned short *__restrict__ isuf, int nblk, int D) {
     for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
         const int o = blk * (D + 1);
         float m = x[o];
         int im = 0;
         ipre[o] = 0;
+#pragma unroll 8
         for (int r = 1; r < D; ++r) {
             if (x[o + r] >= m) { m = x[o + r]; im = r; }
             ipre[o + r] = (unsigned short)im;
@@ -108,6 +136,7 @@ __device__ __forceinline__ void mb_scan_argmax(const float *x, unsigned short *i
         m = x[o + D - 1];
         im = D - 1;
         isuf[o + D - 1] = (unsigned short)im;
+#pragma unroll 8
         for (int r = D - 2; r >= 0; --r) {
             if (x[o + r] > m) { m = x[o + r]; im = r; }
             isuf[o + r] = (unsigned short)im;
@@ -115,21 +144,39 @@ __device__ __forceinline__ void mb_scan_argmax(const float *x, unsigned short *i
     }
 }
 
+// Barrier for LDS hand-offs only: __syncthreads() also drains vmcnt, which would put the latency of the next
+// row's energy loads and of this row's result stores on every phase of the row loop.
+__device__ __forceinline__ void mb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// every boundary position of this thread (j = tid, tid + nthr, ...), as a ROLLED loop: block and offset advance by
+// (nthr / D, nthr % D) without a division; the heavy phase bodies are instantiated once (unrolled x5 they spilled)
+#define MB_FOR_POS(...)                                                                        \
+    {                                                                                          \
+        int blk = blk0, r = r0;                                                                \
+        _Pragma("unroll 1") for (int j = tid; j < P; j += nthr) {                              \
+            const int x = blk * (D + 1) + r;                                                   \
+            __VA_ARGS__                                                                        \
+            r += rstep;                                                                        \
+            blk += bstep;                                                                      \
+            if (r >= D) { r -= D; ++blk; }                                                     \
+        }                                                                                      \
+    }
 constexpr int MB_NPOS = 5;     // boundary positions per thread (P <= 5 * 1024)
 
+template <int VT>
 __global__ __launch_bounds__(MB_THREADS) void mobo_forward_kernel(MoboParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int b = blockIdx.x;
     const int P = p.P, D = p.D, nblk = P / D, PP = P + nblk;     // PP: padded array length
-    float *sE = reinterpret_cast<float *>(smem);   // e_i at boundary position j (energy of the token's last frame j-1)
-    float *sU = sE + PP;                           // la_{i-1}(k) - L_i(k)
-    float *sV = sU + PP;                           // delta_{i-1}(k) - L_i(k)
-    float *sP = sV + PP;                           // block prefix log-sums (of e, then of U)
-    float *sS = sP + PP;                           // block suffix log-sums
-    float *sA = sS + PP;                           // la_{i-1}, then la_i
-    float *sDl = sA + PP;                          // delta
-    unsigned short *iP = reinterpret_cast<unsigned short *>(sDl + PP);      // [PP] prefix argmax of V
+    double *sT = reinterpret_cast<double *>(smem);  // 2^(v - block max), then the block prefix sums (in place)
+    double *sS = sT + PP;                           // block suffix sums
+    float *sE = reinterpret_cast<float *>(sS + PP); // e_i at boundary position j (energy of the token's last frame j-1)
+    float *sV = sE + PP;                            // delta_{i-1}(k) - L_i(k)
+    float *sA = sV + PP;                            // la_{i-1}; la_{i-1}(k) - L_i(k) between steps C and E; then la_i
+    float *sDl = sA + PP;                           // delta
+    float *sM = sDl + PP;                           // [nblk] block maxima (of e, then of U)
+    unsigned short *iP = reinterpret_cast<unsigned short *>(sM + nblk);     // [PP] prefix argmax of V
     unsigned short *iS = iP + PP;                                           // [PP] suffix argmax of V
 
     int I = p.t_xs[b], J = p.t_ys[b];
@@ -165,75 +212,94 @@ __global__ __launch_bounds__(MB_THREADS) void mobo_forward_kernel(MoboParams p) 
         }
     __syncthreads();
     unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
+    const int blk0 = tid / D, r0 = tid - blk0 * D, bstep = nthr / D, rstep = nthr - bstep * D;
+    unsigned enext[MB_NPOS];                       // raw bits of the next row's energies (clamped index: no branch)
+#pragma unroll
+    for (int n = 0; n < MB_NPOS; ++n) {
+        const int jj = pj[n] < 1 ? 1 : (pj[n] > J ? J : pj[n]);
+        enext[n] = mb_load_raw<VT>(p.e, (size_t)b * p.Tx * p.Ty + (jj - 1));
+    }
     for (int i = 0; i < I; ++i) {
         const int hi = J - (I - 1 - i);
         const long long lo64 = (long long)J - (long long)(I - 1 - i) * D;
         const int lo = (lo64 > i + 1) ? (int)lo64 : i + 1;
-        // ---- A: this token's energies at the feasible boundary positions, base-2 ----
+        // ---- A: this token's energies at the feasible boundary positions, base-2 (fetched during the previous
+        //         row: the loads of row i+1 are in flight while row i is computed) ----
         const size_t rowoff = ((size_t)b * p.Tx + i) * p.Ty;
 #pragma unroll
         for (int n = 0; n < MB_NPOS; ++n)
             if (pj[n] >= 0) {
                 const int j = pj[n];
-                sE[pb[n] * (D + 1) + pr[n]] = (j >= lo && j <= hi) ? mb_load(p.e, p.vt, rowoff + (j - 1)) * MB_LOG2E : MB_NEG;
+                sE[pb[n] * (D + 1) + pr[n]] = (j >= lo && j <= hi) ? mb_value<VT>(enext[n]) * MB_LOG2E : MB_NEG;
             }
-        __syncthreads();
+        mb_lds_barrier();
+        if (i + 1 < I) {
+            const size_t nextoff = rowoff + p.Ty;
+#pragma unroll
+            for (int n = 0; n < MB_NPOS; ++n) {
+                const int jj = pj[n] < 1 ? 1 : (pj[n] > J ? J : pj[n]);
+                enext[n] = mb_load_raw<VT>(p.e, nextoff + (jj - 1));
+            }
+        }
         // ---- B: block scans of e ----
-        mb_scan_lse(sE, sP, sS, nblk, D);
-        __syncthreads();
-        // ---- C: normaliser of the step out of k: positions (k, k+D] = rest of k's block + head of the next ----
-#pragma unroll
-        for (int n = 0; n < MB_NPOS; ++n)
-            if (pj[n] >= 0) {
-                const int blk = pb[n], r = pr[n], x = blk * (D + 1) + r;
-                const float S1 = (r + 1 < D) ? sS[x + 1] : MB_NEG;
-                const float S2 = (blk + 1 < nblk) ? sP[(blk + 1) * (D + 1) + r] : MB_NEG;
-                const float L = mb_lse2(S1, S2);
-                const bool live = L > 0.5f * MB_NEG;
-                sU[x] = (live && sA[x] > 0.5f * MB_NEG) ? sA[x] - L : MB_NEG;
-                sV[x] = (live && sDl[x] > 0.5f * MB_NEG) ? sDl[x] - L : MB_NEG;
-            }
-        __syncthreads();
+        mb_block_max(sE, sM, nblk, D);
+        mb_lds_barrier();
+        MB_FOR_POS({ sT[x] = mb_pow2(sE[x] - sM[blk]); });
+        mb_lds_barrier();
+        mb_block_sums(sT, sS, nblk, D);
+        mb_lds_barrier();
+        // ---- C: normaliser of the step out of k: positions (k, k+D] = rest of k's block + head of the next.
+        //         u = la_{i-1}(k) - L replaces la_{i-1}(k) in place (a lane only ever reads its own entry of sA) ----
+        MB_FOR_POS({
+            const double S1 = (r + 1 < D) ? sS[x + 1] : 0.0;
+            const double S2 = (blk + 1 < nblk) ? sT[(blk + 1) * (D + 1) + r] : 0.0;
+            const float L = mb_window(sM[blk], S1, (blk + 1 < nblk) ? sM[blk + 1] : MB_NEG, S2);
+            const bool live = L > 0.5f * MB_NEG;
+            const float a = sA[x], d = sDl[x];
+            sA[x] = (live && a > 0.5f * MB_NEG) ? a - L : MB_NEG;
+            sV[x] = (live && d > 0.5f * MB_NEG) ? d - L : MB_NEG;
+        });
+        mb_lds_barrier();
         // ---- D: block scans of U (sums) and V (argmax) ----
-        mb_scan_lse(sU, sP, sS, nblk, D);
+        mb_block_max(sA, sM, nblk, D);
         mb_scan_argmax(sV, iP, iS, nblk, D);
-        __syncthreads();
+        mb_lds_barrier();
+        MB_FOR_POS({ sT[x] = mb_pow2(sA[x] - sM[blk]); });
+        mb_lds_barrier();
+        mb_block_sums(sT, sS, nblk, D);
+        mb_lds_barrier();
         // ---- E: window [j-D, j) = tail of the previous block + head of j's block ----
-#pragma unroll
-        for (int n = 0; n < MB_NPOS; ++n)
-            if (pj[n] >= 0) {
-                const int j = pj[n], blk = pb[n], r = pr[n], x = blk * (D + 1) + r;
-                float la = MB_NEG, de = MB_NEG;
-                int dur = 0;
-                if (j >= lo && j <= hi) {
-                    const int xp = (blk - 1) * (D + 1) + r;              // same offset, previous block
-                    const float S1 = (blk >= 1) ? sS[xp] : MB_NEG;
-                    const float S2 = (r >= 1) ? sP[x - 1] : MB_NEG;
-                    const float w = mb_lse2(S1, S2);
-                    if (w > 0.5f * MB_NEG) la = sE[x] + w;
-                    // max-product twin: best previous boundary, the larger position on a tie
-                    int kb = -1, kx = 0;
-                    float vb = MB_NEG;
-                    if (blk >= 1) {
-                        const int rr = iS[xp];
-                        kb = (blk - 1) * D + rr;
-                        kx = (blk - 1) * (D + 1) + rr;
-                        vb = sV[kx];
-                    }
-                    if (r >= 1) {
-                        const int rr = iP[x - 1], k2x = blk * (D + 1) + rr;
-                        if (sV[k2x] >= vb) { kb = blk * D + rr; vb = sV[k2x]; }
-                    }
-                    if (kb >= 0 && vb > 0.5f * MB_NEG) { de = sE[x] + vb; dur = j - kb; }
+        MB_FOR_POS({
+            float la = MB_NEG, de = MB_NEG;
+            int dur = 0;
+            if (j >= lo && j <= hi) {
+                const int xp = (blk - 1) * (D + 1) + r;              // same offset, previous block
+                const double S1 = (blk >= 1) ? sS[xp] : 0.0;
+                const double S2 = (r >= 1) ? sT[x - 1] : 0.0;
+                const float w = mb_window((blk >= 1) ? sM[blk - 1] : MB_NEG, S1, sM[blk], S2);
+                if (w > 0.5f * MB_NEG) la = sE[x] + w;
+                // max-product twin: best previous boundary, the larger position on a tie
+                int kb = -1;
+                float vb = MB_NEG;
+                if (blk >= 1) {
+                    const int rr = iS[xp];
+                    kb = (blk - 1) * D + rr;
+                    vb = sV[(blk - 1) * (D + 1) + rr];
                 }
-                if (j <= p.Ty) backb[(size_t)i * (p.Ty + 1) + j] = (unsigned short)dur;
-                if (p.log_alpha && j >= 1 && j <= p.Ty)
-                    p.log_alpha[rowoff + (j - 1)] = (la > 0.5f * MB_NEG) ? la * MB_LN2 : -__builtin_huge_valf();
-                // (this row's la / delta replace the previous row's in place: the windows read sU / sV, not these)
-                sA[x] = la;
-                sDl[x] = de;
+                if (r >= 1) {
+                    const int rr = iP[x - 1];
+                    const float v2 = sV[blk * (D + 1) + rr];
+                    if (v2 >= vb) { kb = blk * D + rr; vb = v2; }
+                }
+                if (kb >= 0 && vb > 0.5f * MB_NEG) { de = sE[x] + vb; dur = j - kb; }
             }
-        __syncthreads();
+            if (j <= p.Ty) backb[(size_t)i * (p.Ty + 1) + j] = (unsigned short)dur;
+            if (p.log_alpha && j >= 1 && j <= p.Ty)
+                p.log_alpha[rowoff + (j - 1)] = (la > 0.5f * MB_NEG) ? la * MB_LN2 : -__builtin_huge_valf();
+            sA[x] = la;                                // (the windows read the scans, not these)
+            sDl[x] = de;
+        });
+        mb_lds_barrier();
     }
     if (p.log_alpha)       // rows past the utterance's own text
         for (size_t n = (size_t)I * p.Ty + tid; n < (size_t)p.Tx * p.Ty; n += nthr)
@@ -341,7 +407,8 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
     const int P = (Ty + 1 + D - 1) / D * D;
     const int nblk = P / D;
     const size_t PP = (size_t)P + nblk;            // one pad word per block
-    const size_t lds = 7 * PP * sizeof(float) + 2 * PP * sizeof(unsigned short) + 16;
+    const size_t lds = 2 * PP * sizeof(double) + 4 * PP * sizeof(float) + (size_t)nblk * sizeof(float) +
+                       2 * PP * sizeof(unsigned short) + 16;
     if (P > MB_NPOS * 1024) return fail(ALIGNER_EDOM, "Ty=%d exceeds %d boundary positions", Ty, MB_NPOS * 1024);
     if (lds > (size_t)device_lds_limit())
         return fail(ALIGNER_EDOM, "Ty=%d with max_duration=%d needs %zu bytes of LDS (limit %d)", Ty, D, lds, device_lds_limit());
@@ -350,10 +417,15 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
     MoboParams p{energies, vt, t_xs, t_ys, log_alpha_out, boundaries_out, durations_out, map_score_out,
                  reinterpret_cast<unsigned short *>(ws + L.back_off), reinterpret_cast<int *>(ws + L.status_off), B, Tx, Ty,
                  D, P};
-    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(mobo_forward_kernel), lds));
     const int threads = P >= 1024 ? 1024 : (P + 63) / 64 * 64;
-    hipLaunchKernelGGL(mobo_forward_kernel, dim3(B), dim3(threads), lds, s, p);
-    ALIGNER_HIP_CHECK(hipGetLastError());
+    auto launch = [&](auto kern) -> int {
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+        hipLaunchKernelGGL(kern, dim3(B), dim3(threads), lds, s, p);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        return ALIGNER_OK;
+    };
+    const int rc = vt == 0 ? launch(mobo_forward_kernel<0>) : vt == 1 ? launch(mobo_forward_kernel<1>) : launch(mobo_forward_kernel<2>);
+    if (rc) return rc;
     if (gamma_out) {
         hipLaunchKernelGGL(mobo_gamma_kernel, dim3(Tx, B), dim3(256), 0, s, log_alpha_out, t_xs, t_ys, gamma_out, Tx, Ty);
         ALIGNER_HIP_CHECK(hipGetLastError());

@@ -51,6 +51,17 @@ v = torch.from_numpy(synth.synth_value(B, Tx, Ty, 5, bits=8, denom=8.0)).to(dev)
 tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
 print("C5 long-form [8,500,4000] bf16 scores: DP durations only %.1f us, with dense int32 path %.1f us" % (
     ev(lambda: aligner_amd.align(v, tx, ty, want_path=False)), ev(lambda: aligner_amd.align(v, tx, ty, path_dtype=torch.int32))))
+# C5 as BASELINE names it: bf16 similarity -> (a) maximum_path and (b) the MoBoAligner boundary search, int32 out
+kk = torch.randn(B, 80, Tx, generator=g).to(dev); qq = torch.randn(B, 80, Ty, generator=g).to(dev)
+lp16, _ = aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16)
+print("C5 [8,80,500,4000]: similarity with bf16 log-probs %.1f us (fp32 log-probs %.1f us); DP on them, durations only %.1f us" % (
+    ev(lambda: aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16)), ev(lambda: aligner_amd.soft_attention(kk, qq, t_x=tx)),
+    ev(lambda: aligner_amd.align(lp16, tx, ty, want_path=False))))
+for D in (16, 32, 64):
+    print("C5 MoBoAligner boundary search [8,500,4000] bf16 energies, max duration %d: boundaries only %.1f us, with log_alpha %.1f us, with gamma %.1f us" % (
+        D, ev(lambda: aligner_amd.boundary_search(lp16, tx, ty, D), it=5, warm=1),
+        ev(lambda: aligner_amd.boundary_search(lp16, tx, ty, D, want_log_alpha=True), it=5, warm=1),
+        ev(lambda: aligner_amd.boundary_search(lp16, tx, ty, D, want_gamma=True), it=5, warm=1)))
 # widened rows at the C2 and C5 shapes
 for (B, Tx, Ty, Cc) in ((64, 200, 1000, 512), (8, 500, 4000, 512)):
     lp = torch.log_softmax(torch.randn(B, Tx, Ty, generator=g), dim=1).to(dev)

@@ -1,0 +1,18 @@
+import os, sys, torch
+sys.path.insert(0, '.')
+import aligner_amd
+dev = torch.device("cuda:0")
+def ev(fn, it=5, warm=1):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it * 1e3
+g = torch.Generator().manual_seed(0)
+B, Tx, Ty = 8, 500, 4000
+lp = (torch.randn(B, Tx, Ty, generator=g) * 2).bfloat16().to(dev)
+tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+for D in (16, 32, 64):
+    print("D=%d: %.1f us" % (D, ev(lambda: aligner_amd.boundary_search(lp, tx, ty, D))))
