@@ -72,3 +72,15 @@ def c4_shard(s: int):
     tx_all, ty_all = synth_lengths(512, Tx, 200, Ty, 4)
     sl = slice(64 * s, 64 * s + 64)
     return value, tx_all[sl].copy(), ty_all[sl].copy()
+
+
+def c4_utterance(g: int):
+    """Utterance g (0..511) of the config-C4 job alone: value[400,2000] (the same numbers as c4_shard(g // 64)[0][g % 64])
+    and its (t_x, t_y) -- so a rank can materialise exactly the utterances a cost-balanced plan hands it."""
+    Tx, Ty = 400, 2000
+    s, b = divmod(int(g), 64)
+    off = b * Tx * Ty
+    k = ((mix(np.arange(off, off + Tx * Ty, dtype=_U), 40 + s) >> _U(40)) & _U(0xFFFF))
+    v = -(k.astype(np.float32) / np.float32(256.0))
+    tx_all, ty_all = synth_lengths(512, Tx, 200, Ty, 4)
+    return v.reshape(Tx, Ty), int(tx_all[g]), int(ty_all[g])

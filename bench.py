@@ -214,6 +214,129 @@ def cpu_baseline(dev, seconds: float = 12.0):
     return out
 
 
+def run_c4(args, world: int, rank: int, local: int):
+    """BASELINE configs[3]: the 512 variable-length utterances ([<=400 tokens, <=2000 frames])
+    aligned across the ranks of one node -- strong scaling: the job is fixed, each rank takes the utterances a
+    longest-processing-time-first plan on the DP cost t_x*(t_y-t_x+1) hands it (aligner_amd/sharded.py), aligns
+    them (durations only) and ONE all-gather of the int32 durations over RCCL restores utterance order on every
+    rank.  A step = the whole job once; value = 512 * steps / time."""
+    import hashlib
+    from aligner_amd import sharded
+    N_UTT, TXM, TYM = 512, 400, 2000
+    dist = None
+    if world > 1 or os.environ.get("ALIGNER_BENCH_FORCE_DIST") == "1":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("ALIGNER_BENCH_REHEARSE") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    _lib.require_gpu()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+    tx_all, ty_all = synth.synth_lengths(N_UTT, TXM, 200, TYM, 4)
+    plan = sharded.lpt_partition(tx_all, ty_all, world)
+    mine = plan[rank]
+    cap = max(len(q) for q in plan)
+    cost = sharded.dp_cost(tx_all, ty_all)
+    loads = [int(cost[q].sum()) for q in plan]
+    # this rank's utterances, resident in HBM (padded batch [cap, 400, 2000])
+    value = torch.zeros((cap, TXM, TYM), dtype=torch.float32, device=dev)
+    for n, gidx in enumerate(mine):
+        value[n] = torch.from_numpy(synth.c4_utterance(int(gidx))[0]).to(dev)
+    t_x = torch.ones(cap, dtype=torch.int32, device=dev)
+    t_y = torch.ones(cap, dtype=torch.int32, device=dev)
+    t_x[:len(mine)] = torch.from_numpy(tx_all[mine]).to(dev)
+    t_y[:len(mine)] = torch.from_numpy(ty_all[mine]).to(dev)
+    dur = torch.zeros((cap, TXM), dtype=torch.int32, device=dev)
+    ws = torch.zeros(lib.aligner_maxpath_workspace_bytes(cap, TXM, TYM) + 256, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((world * cap, TXM), dtype=torch.int32, device=dev)
+    # every rank knows the whole plan: row r*cap + n of `gathered` is utterance plan[r][n]
+    src = np.full(N_UTT, 0, np.int64)
+    for r, q in enumerate(plan):
+        src[q] = r * cap + np.arange(len(q))
+    src_t = torch.from_numpy(src).to(dev)
+    full = torch.zeros((N_UTT, TXM), dtype=torch.int32, device=dev)
+
+    def step():
+        _lib.check(lib.aligner_maxpath_forward_f32(value.data_ptr(), None, 0, t_x.data_ptr(), t_y.data_ptr(), None,
+                                                   dur.data_ptr(), ws.data_ptr(), ws.numel(), cap, TXM, TYM, -1e9, 0,
+                                                   torch.cuda.current_stream(dev).cuda_stream))
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, dur)
+            torch.index_select(gathered, 0, src_t, out=full)
+        else:
+            torch.index_select(dur, 0, src_t, out=full)
+
+    def timed(nsteps):
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for _ in range(args.warmup):
+        step()
+    elapsed = timed(args.steps)
+    # this rank's DP time alone (HIP events), for the load-balance line
+    t_dp = event_time_us(lambda: _lib.check(lib.aligner_maxpath_forward_f32(
+        value.data_ptr(), None, 0, t_x.data_ptr(), t_y.data_ptr(), None, dur.data_ptr(), ws.data_ptr(), ws.numel(),
+        cap, TXM, TYM, -1e9, 0, torch.cuda.current_stream(dev).cuda_stream)), 10, dev)
+    dp_all = [t_dp]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = t_dp
+        dist.all_reduce(t)
+        dp_all = [float(x) for x in t.cpu()]
+    # parity on the timed output: per contiguous 64-utterance shard, the reference's duration hashes
+    ok = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "appendix_a.json")) as f:
+            rec = json.load(f)
+        fh = full.cpu().numpy().astype(np.int32)
+        ok = all(hashlib.sha256(np.ascontiguousarray(fh[64 * s:64 * s + 64]).tobytes()).hexdigest() ==
+                 rec[f"C4-shard{s}"]["dur_sha256"] for s in range(8))
+    except (OSError, KeyError, ValueError):
+        ok = None
+    assert ok is not False, "gathered durations differ from the reference's hashes"
+    if rank == 0:
+        ups = N_UTT * args.steps / elapsed
+        out = {
+            "metric": "aligned utterances/sec, 512 variable-length utterances (T_mel <= 2000) batch-sharded over the GPUs",
+            "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(float(ty_all.sum()) * args.steps / elapsed, 1),
+            "n_gpus": max(world, 1), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: 512 variable-length utterances [<=400 tokens, <=2000 frames] fp32, DP "
+                                   "durations per rank + one RCCL all_gather of int32 durations per pass",
+                       "utterances": N_UTT, "per_rank": cap, "parallelism": f"LPT batch shards x{max(world, 1)}"},
+            "load_balance": {"dp_cost_max_over_mean": round(max(loads) / (sum(loads) / len(loads)), 4),
+                             "dp_kernel_us_per_rank": [round(x, 1) for x in dp_all]},
+            "durations_match_reference_hashes": ok,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,11 +349,19 @@ def main():
                     help="skip the four extra timed regions (spread) and the one-batch-in-flight figure")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 (default): BASELINE configs[1], the headline; c4: configs[3], the 512-utterance ragged job")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.config == "c4":
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        if args.steps == 200 and args.warmup == 20:
+            args.steps, args.warmup = 50, 5              # a pass is ~0.1-1 ms: keep the default run short
+        return run_c4(args, world, rank, local)
     dist = None
     # ALIGNER_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, duration buckets) with one rank
     if args.gpus > 1 or world > 1 or os.environ.get("ALIGNER_BENCH_FORCE_DIST") == "1":

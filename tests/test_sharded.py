@@ -47,9 +47,11 @@ def _worker(rank, world, port, n, Tx, Ty, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [13, 16])
-def test_sharded_equals_single_process(tmp_path, n):
-    world, Tx, Ty = 2, 24, 96
+@pytest.mark.parametrize("world,n", [(2, 13), (2, 16), (4, 13), (4, 3)])
+def test_sharded_equals_single_process(tmp_path, world, n):
+    """world 2 and 4; 13 utterances (shards of 4/3/3/3: padded blocks, index column) and fewer utterances than
+    ranks (an empty shard still takes part in the collective)."""
+    Tx, Ty = 24, 96
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, Tx, Ty, str(tmp_path)), nprocs=world, join=True)
     tx, ty = synth.synth_lengths(n, Tx, Ty // 4, Ty, 9)
