@@ -928,6 +928,8 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     ALIGNER_STAMP(7);
 }
 
+#include "fused_align.inc"
+
 // --------------------------------------------------------------------------
 // starts -> dense 0/1 path in the caller's dtype (the reference's return value,
 // __init__.py:21).  Pure streaming store: path[b,x,y] = starts[x] <= y < starts[x+1].
@@ -1293,6 +1295,46 @@ int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, co
                         float max_neg_val, int flags, void *stream) {
     return aligner_maxpath(value, ALIGNER_DT_F32, mask, mask_dtype, t_xs, t_ys, path_out, path_dtype, tok_out, dur_out,
                            ws, ws_bytes, B, Tx, Ty, max_neg_val, flags, stream);
+}
+
+int aligner_fused_align_f32(const float *keys, const float *queries, const int32_t *t_xs, const int32_t *t_ys,
+                            float *logp_out, int32_t *tok_out, int32_t *dur_out, void *ws, size_t ws_bytes, int B,
+                            int C, int Tx, int Ty, float temperature, int sim, float max_neg_val, void *stream) {
+    if (!keys || !queries || !t_xs || !t_ys || !ws) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || C < 1 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d C=%d Tx=%d Ty=%d", B, C, Tx, Ty);
+    if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
+    if (C > 16 * FA_KS || Tx > RPW * FA_NW || Ty > 64 * TC)
+        return fail(ALIGNER_EDOM, "fused form: C <= %d, Tx <= %d, Ty <= %d (C=%d Tx=%d Ty=%d)", 16 * FA_KS, RPW * FA_NW,
+                    64 * TC, C, Tx, Ty);
+    if (!(max_neg_val - max_neg_val == 0.0f)) return fail(ALIGNER_EINVAL, "max_neg_val must be finite");
+    if (B == 0) return ALIGNER_OK;
+    const WsLayout L = ws_layout(B, Tx, Ty);
+    if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
+    unsigned char *wsb = static_cast<unsigned char *>(ws);
+    FusedParams fp;
+    fp.keys = keys; fp.queries = queries; fp.logp = logp_out; fp.C = C; fp.temperature = temperature; fp.sim = sim;
+    MaxpathParams &p = fp.mp;
+    p.value = nullptr; p.mask = nullptr;
+    p.t_xs = t_xs; p.t_ys = t_ys;
+    p.starts = reinterpret_cast<int *>(wsb + L.starts_off);
+    p.tok = tok_out; p.dur = dur_out;
+    p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
+    p.status = reinterpret_cast<int *>(wsb + L.status_off);
+    p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
+    p.neg = max_neg_val; p.flags = 0;
+    p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0; p.force_exact = 0;
+    p.stamps = g_debug_stamps;
+    const size_t lds_max = (size_t)lds_limit();
+    const FusedLds FL = fused_lds_layout();
+    p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
+    if (p.WT <= 0) return fail(ALIGNER_EDOM, "Tx=%d/Ty=%d too large for the backtrack window", Tx, Ty);
+    size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
+    if (lds < (size_t)FL.total) lds = FL.total;
+    if (lds > lds_max) return fail(ALIGNER_EDOM, "fused form needs %zu bytes of LDS (limit %zu)", lds, lds_max);
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fused_align_kernel), lds));
+    hipLaunchKernelGGL(fused_align_kernel, dim3(B), dim3(FA_NW * 128), lds, static_cast<hipStream_t>(stream), fp);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
 }
 
 int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {
