@@ -82,6 +82,7 @@ struct MaxpathParams {
     float neg;
     int flags;
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable)
+    float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
 };
 
 // Development aid: lane 0 of every wave drops a shader-clock stamp (slot 6/7 the
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask
 // --------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t status_off, len_off, starts_off, bits_off, total;
+    size_t status_off, len_off, starts_off, bits_off, dump_off, total;
     int NT, ROWS;
 };
 
@@ -1013,7 +1014,8 @@ static WsLayout ws_layout(int B, int Tx, int Ty) {
     L.len_off = WS_HDR_BYTES;
     L.starts_off = align_up(L.len_off + (size_t)2 * B * sizeof(int), 256);
     L.bits_off = align_up(L.starts_off + (size_t)B * (Tx + 1) * sizeof(int), 256);
-    L.total = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
+    L.dump_off = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
+    L.total = align_up(L.dump_off + (size_t)B * 4 * 64 * sizeof(float), 256);
     return L;
 }
 
@@ -1119,6 +1121,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0;
     p.force_exact = !(neg - neg == 0.0f);            // NaN / inf max_neg_val
     p.stamps = g_debug_stamps;
+    p.dump = nullptr;
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
@@ -1324,6 +1327,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     p.neg = max_neg_val; p.flags = 0;
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0; p.force_exact = 0;
     p.stamps = g_debug_stamps;
+    p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
     const size_t lds_max = (size_t)lds_limit();
     const FusedLds FL = fused_lds_layout();
     p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
