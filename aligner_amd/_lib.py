@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaligner_amd.so")
+# ALIGNER_AMD_LIB: development override (A/B builds of the same library); the default is the in-tree build
+LIB_PATH = os.environ.get("ALIGNER_AMD_LIB") or os.path.join(_HERE, "lib", "libaligner_amd.so")
 
 # dtype codes (include/aligner_amd.h)
 DT_F32, DT_F16, DT_BF16, DT_F64, DT_I32, DT_U8, DT_I64 = range(7)

@@ -665,6 +665,13 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
     }
 }
 
+// Development aid: -DALIGNER_EXP_NOBARRIER drops the phase barriers (results are garbage); the waves' own
+// instruction streams can then be timed apart (stamp 4, tools/stamps.py, tools/exp_build.sh).
+#ifdef ALIGNER_EXP_NOBARRIER
+#define PHASE_BARRIER() do {} while (0)
+#else
+#define PHASE_BARRIER() __syncthreads()
+#endif
 template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT>
 __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -716,7 +723,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             const int brow = (lane == 0) ? p.ROWS - 1 : row;            // decision word column (ghost lane: padding)
             unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + brow;
 
-            for (int i = 0; i < t_lo + w + 1; ++i) __syncthreads();
+            for (int i = 0; i < t_lo + w + 1; ++i) PHASE_BARRIER();
             for (int t = t_lo; t <= t_hi; ++t) {
                 // one ds_read_b128 per 4 frames; the padded row stride (9 x 16 B) makes the 16-lane
                 // groups of a b128 read hit 16 different 16-byte slots: conflict-free
@@ -752,9 +759,9 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     gbits[(size_t)t * p.ROWS] = bits;
                 }
                 bits = 0u;
-                __syncthreads();
+                PHASE_BARRIER();
             }
-            for (int i = 0; i < ntb + NW - w - t_hi - 2; ++i) __syncthreads();
+            for (int i = 0; i < ntb + NW - w - t_hi - 2; ++i) PHASE_BARRIER();
         } else {
             // ------------------------------ loader wave -------------------------------
             if (active) {
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     };
     #pragma unroll
                     for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
-                    for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                    for (int i = 0; i < t_lo + w; ++i) PHASE_BARRIER();
                     for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
     #pragma unroll
                         for (int d = 0; d < DEPTH; ++d) {
@@ -834,7 +841,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                             __builtin_amdgcn_sched_barrier(0);
                             issue(buf[d], t + DEPTH);
                             __builtin_amdgcn_sched_barrier(0);
-                            if (t <= t_hi) __syncthreads();
+                            if (t <= t_hi) PHASE_BARRIER();
                         }
                     }
                 } else {
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     };
 #pragma unroll
                     for (int d = 0; d < DEPTH; ++d) issue(d, t_lo + d);
-                    for (int i = 0; i < t_lo + w; ++i) __syncthreads();
+                    for (int i = 0; i < t_lo + w; ++i) PHASE_BARRIER();
                     for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
 #pragma unroll
                         for (int d = 0; d < DEPTH; ++d) {
@@ -906,16 +913,17 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                             __builtin_amdgcn_sched_barrier(0);
                             issue(d, t + DEPTH);
                             __builtin_amdgcn_sched_barrier(0);
-                            if (t <= t_hi) __syncthreads();
+                            if (t <= t_hi) PHASE_BARRIER();
                         }
                     }
                 }
                 if (absbits(nf) >= 0x7F800000u) flagp[0] = 1;   // benign race: every writer stores 1
-                for (int i = 0; i < ntb + NW - w - t_hi - 1; ++i) __syncthreads();
+                for (int i = 0; i < ntb + NW - w - t_hi - 1; ++i) PHASE_BARRIER();
             } else {
-                for (int i = 0; i < ntb + NW; ++i) __syncthreads();
+                for (int i = 0; i < ntb + NW; ++i) PHASE_BARRIER();
             }
         }
+        ALIGNER_STAMP(4);
         __syncthreads();
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the

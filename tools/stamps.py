@@ -29,6 +29,7 @@ print("waves", nw, "shader clock GHz (median)", round(float(np.median(clk)), 3))
 for k in (1, 2, 3, 5):
     d = s[:, 0, k] - s[:, 0, 0]
     print(f"{names[k]:>11}: wave0 cycles since entry  median {np.median(d):9.0f}  min {d.min():9.0f}  max {d.max():9.0f}   ({np.median(d)/np.median(clk)/1e3:6.2f} us)")
+print("per-wave own stream done, before the closing barrier (b=0):", [int(s[0, w, 4] - s[0, 0, 0]) for w in range(nw)])
 print("per-wave fwd_done (b=0):", [int(s[0, w, 1] - s[0, 0, 0]) for w in range(nw)])
 start = s[:, 0, 0]
 for w in range(nw):
