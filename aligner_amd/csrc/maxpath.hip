@@ -81,6 +81,7 @@ struct MaxpathParams {
     int force_exact;        // skip the v_max sweep (non-finite max_neg_val)
     float neg;
     int flags;
+    int lds_total;          // bytes of LDS the launch asked for (store_outputs: is there room for its scratch?)
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable)
     float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
 };
@@ -163,19 +164,57 @@ __device__ __forceinline__ bool tile_in_band(int t, int r0, int nrows, int tx, i
     return (TC * t + TC - 1 >= y_lo) && (TC * t <= y_hi);
 }
 
-// Token starts -> the caller's outputs.  starts[x] = first frame of token x for
-// x < t_x and t_y for t_x <= x <= Tx, so durations are plain differences and a
-// frame's token is found by bisection.
-__device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, const int *startsL) {
+// Token starts -> the caller's outputs.  starts[x] = first frame of token x for x < t_x and t_y for t_x <= x <= Tx,
+// so durations are plain differences.  A frame's token is the number of tokens 1 .. t_x-1 that start at or before
+// it: the starts are marked in a bit string over the frames (LDS scratch behind the starts), a single wave turns
+// the words' population counts into running totals, and a frame costs one masked popcount -- no search.  (Without
+// room for the bit string -- a very long mel axis on a small workgroup -- each frame bisects the starts.)
+__device__ __forceinline__ int starts_words_of(int Tx) { return ((Tx + 1 + 63) / 64) * 64 + 64; }
+
+__device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, int *startsL,
+                                              bool distinct_starts = true) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
         for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
-    if (p.tok)
+    if (!p.tok) return;
+    const int nmw = (ty + 31) >> 5;                        // words of the bit string
+    unsigned *mark = reinterpret_cast<unsigned *>(startsL + starts_words_of(p.Tx));
+    int *before = reinterpret_cast<int *>(mark + nmw);    // set bits in the words before word j
+    // (the t_x > t_y compatibility result has rows that own no frame: equal starts, so it takes the search)
+    const bool room = distinct_starts && (size_t)(starts_words_of(p.Tx) + 2 * nmw) * 4 <= (size_t)p.lds_total;
+    if (room) {
+        for (int j = tid; j < nmw; j += nthreads) mark[j] = 0u;
+        __syncthreads();
+        for (int x = 1 + tid; x < tx; x += nthreads) {
+            const int st = startsL[x];                      // strictly increasing in x: every bit is set once
+            atomicOr(&mark[st >> 5], 1u << (st & 31));
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int per = (nmw + 63) >> 6, j0 = tid * per;
+            int mine = 0;
+            for (int j = j0; j < j0 + per && j < nmw; ++j) mine += __builtin_popcount(mark[j]);
+            int run = mine;                                 // inclusive scan over the 64 lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(run, d);
+                if (tid >= d) run += up;
+            }
+            run -= mine;
+            for (int j = j0; j < j0 + per && j < nmw; ++j) { before[j] = run; run += __builtin_popcount(mark[j]); }
+        }
+        __syncthreads();
+        for (int y = tid; y < p.Ty; y += nthreads) {
+            int t = -1;
+            if (y < ty) t = before[y >> 5] + __builtin_popcount(mark[y >> 5] & ((2u << (y & 31)) - 1u));
+            p.tok[(size_t)b * p.Ty + y] = t;
+        }
+    } else {
         for (int y = tid; y < p.Ty; y += nthreads) {
             int t = -1;
             if (y < ty) {
-                int lo = 0, hi = tx - 1;              // last x with starts[x] <= y
+                int lo = 0, hi = tx - 1;                  // last x with starts[x] <= y
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (startsL[mid] <= y) lo = mid; else hi = mid - 1;
@@ -184,6 +223,7 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
             }
             p.tok[(size_t)b * p.Ty + y] = t;
         }
+    }
 }
 
 // Outputs for the degenerate modes (whole block, uniform): no ones at all, or the reference's t_x > t_y
@@ -219,7 +259,7 @@ __device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, 
         // rows 0..index: `index` owns frames [0, start of index+1), the rows above it nothing
     }
     __syncthreads();
-    store_outputs(p, b, tx, mode == MODE_COMPAT ? ty : 0, startsL);      // no frame has a token in the empty modes
+    store_outputs(p, b, tx, mode == MODE_COMPAT ? ty : 0, startsL, false);   // no frame has a token in the empty modes
 }
 
 // --------------------------------------------------------------------------
@@ -395,7 +435,7 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
     const int nthreads = blockDim.x;
     const int RP = row_pitch(p.ROWS);
     int *startsL = reinterpret_cast<int *>(smem);
-    const int starts_words = ((p.Tx + 1 + 63) / 64) * 64 + 64;
+    const int starts_words = starts_words_of(p.Tx);
     unsigned *win = reinterpret_cast<unsigned *>(smem) + starts_words;
     const bool in_lds = p.bits_in_lds != 0;
     if (in_lds) win = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);
@@ -1042,6 +1082,7 @@ static int pick_window(int NT, int ROWS, int Tx, size_t budget) {
 
 template <typename K>
 static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, MaxpathParams p) {
+    p.lds_total = (int)lds;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), lds));
     hipLaunchKernelGGL(kernel, grid, block, lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
@@ -1343,6 +1384,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
     if (lds < (size_t)FL.total) lds = FL.total;
     if (lds > lds_max) return fail(ALIGNER_EDOM, "fused form needs %zu bytes of LDS (limit %zu)", lds, lds_max);
+    p.lds_total = (int)lds;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fused_align_kernel), lds));
     hipLaunchKernelGGL(fused_align_kernel, dim3(B), dim3(FA_NW * 128), lds, static_cast<hipStream_t>(stream), fp);
     ALIGNER_HIP_CHECK(hipGetLastError());
