@@ -405,3 +405,21 @@ def test_sharded_product_path_single_rank(appendix_a, dev):
     finally:
         dist.destroy_process_group()
     assert np.array_equal(got.cpu().numpy(), arrays["c4_s0_dur"].astype(np.int32))
+
+
+def test_token_index_on_a_very_long_mel_axis(dev):
+    """tok[b, y] comes from a bit string of the token starts kept in LDS behind the starts; with ~90 000 frames on
+    a narrow workgroup there is no room for it and every frame bisects the starts instead.  Both roads, same answer."""
+    rng = np.random.default_rng(5)
+    for (B, Tx, Ty) in [(2, 3, 90000), (1, 40, 70001)]:
+        v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+        ty = np.array([Ty] + [int(rng.integers(Tx, Ty)) for _ in range(B - 1)], np.int32)
+        tx = np.array([Tx] + [int(rng.integers(1, Tx + 1)) for _ in range(B - 1)], np.int32)
+        want = _oracle_path(v, tx, ty)
+        for kw in ({}, {"force_generic": True}):
+            p, tok, dur = _hip(v, tx, ty, dev, **kw)
+            assert np.array_equal(p, want), (B, Tx, Ty, kw)
+            _check_consistency(p, tok, dur, tx, ty)
+
+
+
