@@ -515,6 +515,10 @@ def main():
                     "kernel_us": round(kernels[dom]["us"], 2), "algorithmic_bytes": kernels[dom]["bytes"],
                     # the DP launches one 8-wave workgroup per utterance: waves resident / wave slots of the chip
                     "dp_wave_occupancy": round(B * 8 / (256 * 32), 4),
+                    # informational: this launch runs on B of the 256 CUs, and one CU takes in at most
+                    # ~64 GB/s (measured: the kernel's loader waves running free; the guide's 66-73 GB/s for L2-
+                    # resident rows) -- the memory bound of THIS launch is B x 64 GB/s, not the chip's peak
+                    "launch_fetch_bound_GBps": round(min(B, 256) * 64.0, 1),
                     "all_kernels": {k: {"us": round(v["us"], 2),
                                         "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)}
                                     for k, v in kernels.items()}}
