@@ -13,7 +13,7 @@ tok = torch.empty((B, Ty), dtype=torch.int32, device=dev); dur = torch.empty((B,
 ws = torch.zeros(lib.aligner_maxpath_workspace_bytes(B, Tx, Ty) + 256, dtype=torch.uint8, device=dev)
 st = torch.zeros((B, 16, 16), dtype=torch.int64, device=dev)
 def run():
-    _lib.check(lib.aligner_maxpath_forward_f32(v.data_ptr(), None, 0, tx.data_ptr(), ty.data_ptr(), tok.data_ptr(), dur.data_ptr(), ws.data_ptr(), ws.numel(), B, Tx, Ty, -1e9, 0, torch.cuda.current_stream().cuda_stream))
+    _lib.check(lib.aligner_maxpath_forward_f32(v.data_ptr(), None, 0, tx.data_ptr(), ty.data_ptr(), tok.data_ptr(), dur.data_ptr(), ws.data_ptr(), ws.numel(), B, Tx, Ty, -1e9, int(os.environ.get('STAMP_FLAGS', '0')), torch.cuda.current_stream().cuda_stream))
 for _ in range(5): run()
 torch.cuda.synchronize()
 lib.aligner_debug_set_stamps(st.data_ptr())
