@@ -1,0 +1,172 @@
+"""Out-of-bounds WRITE check of the HIP kernels (the reference compiles its loops with
+boundscheck / wraparound off, core.pyx:7-8,38-39, and asks the rebuild to switch checks on in tests).
+
+GPU AddressSanitizer is not available on this pool, so every buffer a kernel writes (dense path, token index,
+durations, workspace, log-probs) is carved out of a larger allocation with canary bands on both sides and the
+kernels are called through the C ABI on the interior pointers: a single stray store into a band fails the test.
+Stray READS are not visible this way; the kernels' tile loaders use buffer resources sized to the utterance (reads
+past it return 0), and the CPU restatement runs under -fsanitize=address,undefined (tests/test_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from aligner_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+BAND = 4096            # bytes of canary on either side
+CANARY = 0xA5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+class Fenced:
+    """nbytes of device memory with a canary band before and after it."""
+
+    def __init__(self, nbytes, dev, align=256):
+        self.n = int(nbytes)
+        pad = (-self.n) % align
+        self.buf = torch.full((BAND + self.n + pad + BAND,), CANARY, dtype=torch.uint8, device=dev)
+        self.lo, self.hi = BAND, BAND + self.n
+        assert self.buf.data_ptr() % 256 == 0
+        self.buf[self.lo:self.hi] = 0
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.lo
+
+    def view(self, dtype, shape):
+        return self.buf[self.lo:self.hi].view(dtype).reshape(shape)
+
+    def intact(self):
+        return bool((self.buf[:self.lo] == CANARY).all()) and bool((self.buf[self.hi:] == CANARY).all())
+
+
+SHAPES = [(1, 1, 1), (3, 7, 13), (2, 63, 64), (4, 64, 257), (2, 127, 1000), (3, 200, 1001), (2, 253, 300),
+          (1, 300, 700), (2, 505, 2100), (1, 600, 650)]
+
+
+@pytest.mark.parametrize("B,Tx,Ty", SHAPES)
+@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE])
+def test_alignment_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, flags):
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 1000 + Tx + Ty)
+    value = torch.from_numpy(synth.synth_value(B, Tx, Ty, seed=Tx + Ty)).to(dev)
+    ty = rng.integers(max(1, Ty // 2), Ty + 1, B).astype(np.int32)
+    tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
+    tx[0], ty[0] = Tx if Tx <= Ty else Ty, Ty
+    d_tx, d_ty = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    wsb = lib.aligner_maxpath_workspace_bytes(B, Tx, Ty)
+    ws, path = Fenced(wsb, dev), Fenced(B * Tx * Ty * 4, dev)
+    tok, dur = Fenced(B * Ty * 4, dev), Fenced(B * Tx * 4, dev)
+    _lib.check(lib.aligner_maxpath_f32(value.data_ptr(), None, 0, d_tx.data_ptr(), d_ty.data_ptr(), path.ptr, _lib.DT_I32,
+                                       tok.ptr, dur.ptr, ws.ptr, wsb, B, Tx, Ty, -1e9, flags,
+                                       torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for name, f in (("workspace", ws), ("path", path), ("tok", tok), ("durations", dur)):
+        assert f.intact(), f"{name}: a kernel wrote outside its buffer"
+    # and the result is the right one (the fences did not move anything)
+    from oracle import maxpath_oracle as O
+    want = np.zeros((B, Tx, Ty), np.int32)
+    O.maximum_path_c(want, value.cpu().numpy().copy(), tx, ty, -1e9)
+    assert np.array_equal(path.view(torch.int32, (B, Tx, Ty)).cpu().numpy(), want)
+    assert np.array_equal(dur.view(torch.int32, (B, Tx)).cpu().numpy(), want.sum(2))
+
+
+@pytest.mark.parametrize("B,C,Tx,Ty", [(2, 80, 50, 130), (3, 80, 200, 1000), (1, 16, 33, 65), (2, 80, 257, 300),
+                                       (1, 80, 500, 1030)])
+@pytest.mark.parametrize("logp_dt", [_lib.DT_F32, _lib.DT_BF16])
+def test_similarity_writes_stay_inside_their_buffers(dev, B, C, Tx, Ty, logp_dt):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + Tx + Ty)
+    k = torch.randn(B, C, Tx, generator=g).to(dev)
+    q = torch.randn(B, C, Ty, generator=g).to(dev)
+    t_x = torch.tensor([Tx] + [max(1, Tx - 7 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    wsb = lib.aligner_softattn_workspace_bytes(B, C, Tx)
+    ws = Fenced(max(wsb, 256), dev)
+    esz = 4 if logp_dt == _lib.DT_F32 else 2
+    logp = Fenced(B * Tx * Ty * esz, dev)
+    _lib.check(lib.aligner_softattn(k.data_ptr(), q.data_ptr(), t_x.data_ptr(), None, logp.ptr, logp_dt, None, ws.ptr, wsb,
+                                    B, C, Tx, Ty, 0.0005, _lib.SIM_L2, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert logp.intact(), "softattn wrote outside the log-prob buffer"
+    assert ws.intact(), "softattn wrote outside its workspace"
+    out = logp.view(torch.float32 if esz == 4 else torch.bfloat16, (B, Tx, Ty)).float()
+    assert bool(torch.isfinite(out[0]).all())            # utterance 0 uses every text row: no masked (-inf) row
+    col = torch.logsumexp(out[0], dim=0)
+    assert float(col.abs().max()) < (1e-3 if esz == 4 else 5e-2)
+
+
+@pytest.mark.parametrize("B,Tx,Ty", [(2, 9, 40), (3, 63, 200), (2, 200, 1000), (2, 260, 400), (1, 505, 1100), (1, 700, 900)])
+def test_forward_sum_prior_regulator_writes_stay_inside_their_buffers(dev, B, Tx, Ty):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tx * 7 + Ty)
+    logp = torch.log_softmax(torch.randn(B, Tx, Ty, generator=g), dim=1).to(dev)
+    t_x = torch.tensor([Tx] + [max(1, Tx - 5 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    t_y = torch.tensor([Ty] + [max(Tx, Ty - 11 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    wsb = lib.aligner_forward_sum_workspace_bytes(B, Tx, Ty)
+    ws, loss, grad = Fenced(wsb, dev), Fenced(B * 4, dev), Fenced(B * Tx * Ty * 4, dev)
+    _lib.check(lib.aligner_forward_sum_f32(logp.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), loss.ptr, grad.ptr, ws.ptr, wsb,
+                                           B, Tx, Ty, s))
+    prior = Fenced(B * Tx * Ty * 4, dev)
+    _lib.check(lib.aligner_beta_binomial_prior_f32(t_x.data_ptr(), t_y.data_ptr(), prior.ptr, B, Tx, Ty, 1.0, s))
+    C = 24
+    h = torch.randn(B, C, Tx, generator=g).to(dev)
+    dur = torch.zeros((B, Tx), dtype=torch.int32, device=dev)
+    dur[:, 0] = t_y - (t_x - 1)
+    for b in range(B):
+        dur[b, 1:int(t_x[b])] = 1
+    out, tok = Fenced(B * C * Ty * 4, dev), Fenced(B * Ty * 4, dev)
+    _lib.check(lib.aligner_regulate_f32(h.data_ptr(), dur.data_ptr(), out.ptr, tok.ptr, B, C, Tx, Ty, s))
+    torch.cuda.synchronize()
+    for name, f in (("forward-sum workspace", ws), ("loss", loss), ("grad", grad), ("prior", prior), ("regulated", out),
+                    ("regulator tok", tok)):
+        assert f.intact(), f"{name}: a kernel wrote outside its buffer"
+    assert bool(torch.isfinite(loss.view(torch.float32, (B,))).all())
+    post = -grad.view(torch.float32, (B, Tx, Ty))[0, :, :int(t_y[0])].sum(0)       # a frame's posterior sums to 1
+    assert float((post - 1).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("B,Tx,Ty,D", [(2, 5, 9, 3), (2, 40, 300, 16), (1, 100, 600, 7), (2, 64, 257, 32)])
+def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tx + Ty + D)
+    e = torch.randn(B, Tx, Ty, generator=g).to(dev)
+    t_x = torch.full((B,), Tx, dtype=torch.int32, device=dev)
+    t_y = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+    wsb = lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty)
+    ws, bnd, dur, sc = Fenced(wsb, dev), Fenced(B * Tx * 4, dev), Fenced(B * Tx * 4, dev), Fenced(B * 4, dev)
+    la, gm = Fenced(B * Tx * Ty * 4, dev), Fenced(B * Tx * Ty * 4, dev)
+    _lib.check(lib.aligner_boundary_search(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, bnd.ptr, dur.ptr, sc.ptr,
+                                           la.ptr, gm.ptr, ws.ptr, wsb, B, Tx, Ty, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for name, f in (("workspace", ws), ("boundaries", bnd), ("durations", dur), ("score", sc), ("log_alpha", la), ("gamma", gm)):
+        assert f.intact(), f"{name}: a kernel wrote outside its buffer"
+    d = dur.view(torch.int32, (B, Tx))
+    assert bool((d >= 1).all()) and bool((d <= D).all()) and bool((d.sum(1) == Ty).all())
+
+
+@pytest.mark.parametrize("B,C,Tx,Ty", [(2, 80, 50, 130), (2, 80, 200, 1000), (1, 80, 252, 2048)])
+def test_fused_kernel_writes_stay_inside_their_buffers(dev, B, C, Tx, Ty):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(C + Tx + Ty)
+    k = torch.randn(B, C, Tx, generator=g).to(dev)
+    q = torch.randn(B, C, Ty, generator=g).to(dev)
+    t_x = torch.tensor([Tx] + [max(1, Tx - 9 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    t_y = torch.tensor([Ty] + [max(Tx, Ty - 13 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    wsb = lib.aligner_maxpath_workspace_bytes(B, Tx, Ty)
+    ws, logp = Fenced(wsb, dev), Fenced(B * Tx * Ty * 4, dev)
+    tok, dur = Fenced(B * Ty * 4, dev), Fenced(B * Tx * 4, dev)
+    _lib.check(lib.aligner_fused_align_f32(k.data_ptr(), q.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), logp.ptr, tok.ptr, dur.ptr,
+                                           ws.ptr, wsb, B, C, Tx, Ty, 0.0005, _lib.SIM_L2, -1e9,
+                                           torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for name, f in (("workspace", ws), ("logp", logp), ("tok", tok), ("durations", dur)):
+        assert f.intact(), f"{name}: the fused kernel wrote outside its buffer"
+    assert bool((dur.view(torch.int32, (B, Tx)).sum(1) == t_y).all())
