@@ -228,6 +228,10 @@ def run_c4(args, world: int, rank: int, local: int):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                                  # the one-rank form of the multi-rank path, started by hand
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         if os.environ.get("ALIGNER_BENCH_REHEARSE") == "1":
             local = 0
             torch.cuda.set_device(0)
@@ -370,6 +374,10 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                                  # the one-rank form of the multi-rank path, started by hand
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29531")
         # rehearsal hook: ALIGNER_BENCH_REHEARSE=1 runs all ranks on GPU 0 over gloo (a 1-GPU box cannot
         # host an RCCL group with more than one rank); the driver's real runs use RCCL, one GPU per rank
         if os.environ.get("ALIGNER_BENCH_REHEARSE") == "1":
