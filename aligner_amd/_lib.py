@@ -21,6 +21,7 @@ F_STRICT_MASK = 1
 F_COMPAT_TXGTTY = 2
 F_FORCE_GENERIC = 4
 F_NO_PREV_TABLE = 16
+F_WRITE_Q = 64
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2

@@ -81,6 +81,7 @@ struct MaxpathParams {
     int force_exact;        // skip the v_max sweep (non-finite max_neg_val)
     float neg;
     int flags;
+    float *qout;            // ALIGNER_F_WRITE_Q: the running scores Q go back into the score block, as core.pyx:30 (nullable)
     int lds_total;          // bytes of LDS the launch asked for (store_outputs: is there room for its scratch?)
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable)
     float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
@@ -532,6 +533,9 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
                 float v = load_score<VT>(p.value, ubase + (size_t)x * p.Ty + y);
                 if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.Ty + y));
                 q[r] = (adv ? up : cur) + v;                       // core.pyx:30
+                // the reference overwrites value[x, y] with Q inside its band only (core.pyx:18,30); cells outside
+                // it keep their scores.  In place: this thread alone reads and writes the cell.
+                if (p.qout && x <= y && x >= tx + y - ty) p.qout[ubase + (size_t)x * p.Ty + y] = q[r];
                 // backtrack predicate (core.pyx:34): the diagonal move is forced whatever the scores
                 bits[r] = (bits[r] << 1) | ((adv || x == y) ? 1u : 0u);
                 dst[x + 1] = q[r];
@@ -1171,6 +1175,14 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.force_exact = !(neg - neg == 0.0f);            // NaN / inf max_neg_val
     p.stamps = g_debug_stamps;
     p.dump = nullptr;
+    p.qout = nullptr;
+    if (flags & ALIGNER_F_WRITE_Q) {
+        if (vt != VT_F32 || (flags & ALIGNER_F_STRICT_MASK))
+            return fail(ALIGNER_EINVAL, "ALIGNER_F_WRITE_Q takes fp32 scores without a strict mask (maximum_path_c's contract)");
+        p.qout = const_cast<float *>(static_cast<const float *>(value));
+        flags |= ALIGNER_F_FORCE_GENERIC;           // the pipelined kernel never materialises Q
+        p.flags = flags;
+    }
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
@@ -1377,6 +1389,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0; p.force_exact = 0;
     p.stamps = g_debug_stamps;
     p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
+    p.qout = nullptr;
     const size_t lds_max = (size_t)lds_limit();
     const FusedLds FL = fused_lds_layout();
     p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
@@ -1400,7 +1413,7 @@ int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {
     return ALIGNER_OK;
 }
 
-int aligner_maxpath_host_f32(int32_t *paths, const float *values, const int32_t *t_xs,
+int aligner_maxpath_host_f32(int32_t *paths, float *values, const int32_t *t_xs,
                              const int32_t *t_ys, int B, int Tx, int Ty, float max_neg_val, int flags) {
     if (!paths || !values || !t_xs || !t_ys) return fail(ALIGNER_EINVAL, "null pointer");
     if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
@@ -1431,6 +1444,7 @@ int aligner_maxpath_host_f32(int32_t *paths, const float *values, const int32_t 
                                  static_cast<int *>(d_len) + B, d_path, ALIGNER_DT_I32, nullptr, nullptr,
                                  d_ws, wsb, B, Tx, Ty, max_neg_val, flags, nullptr);
     HOST_TRY(hipMemcpy(paths, d_path, n * 4, hipMemcpyDeviceToHost));
+    if (flags & ALIGNER_F_WRITE_Q) HOST_TRY(hipMemcpy(values, d_val, n * 4, hipMemcpyDeviceToHost));
 #undef HOST_TRY
     if (d_val) (void)hipFree(d_val);
     if (d_path) (void)hipFree(d_path);

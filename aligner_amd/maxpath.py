@@ -208,13 +208,15 @@ def maximum_path(value: torch.Tensor, mask: torch.Tensor, *, mask_is_prefix: boo
 
 
 def maximum_path_c(paths: np.ndarray, values: np.ndarray, t_xs: np.ndarray, t_ys: np.ndarray,
-                   max_neg_val: float = -1e9) -> None:
+                   max_neg_val: float = -1e9, write_q: bool = True) -> None:
     """Drop-in for monotonic_align.core.maximum_path_c (core.pyx:40-45) on numpy buffers.
 
     Same argument checks as the Cython memoryview glue (exact dtypes, ndim,
     C-contiguity, writability -> ValueError).  `paths` is overwritten with the
-    path.  Unlike the reference, `values` is left untouched (the reference turns
-    it into the running score Q in place; nothing downstream reads that).
+    path and, as in the reference, `values` with the running score Q inside every
+    utterance's band (core.pyx:30), bit for bit.  write_q=False leaves `values`
+    untouched and takes the fast kernel (nothing downstream of the reference's own
+    wrapper reads Q, __init__.py:20-21).
     """
     for a, dt, nd in ((paths, np.int32, 3), (values, np.float32, 3), (t_xs, np.int32, 1), (t_ys, np.int32, 1)):
         if not isinstance(a, np.ndarray):
@@ -234,7 +236,8 @@ def maximum_path_c(paths: np.ndarray, values: np.ndarray, t_xs: np.ndarray, t_ys
     if b == 0 or tx == 0 or ty == 0:
         return
     rc = _lib.load().aligner_maxpath_host_f32(paths.ctypes.data, values.ctypes.data, t_xs.ctypes.data,
-                                               t_ys.ctypes.data, b, tx, ty, float(max_neg_val), 0)
+                                               t_ys.ctypes.data, b, tx, ty, float(max_neg_val),
+                                               _lib.F_WRITE_Q if write_q else 0)
     if rc == -33:
         raise ValueError(_lib.load().aligner_last_error().decode())
     _lib.check(rc)

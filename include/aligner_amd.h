@@ -64,6 +64,11 @@ extern "C" {
 
 #define ALIGNER_F_NO_PREV_TABLE 16 /* testing: do not keep the backtrack's second LDS table (the walk then
                                       takes the flag-and-retry steps it uses for long utterances)   */
+#define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside
+                                      the band, in place, exactly as the reference does (core.pyx:18,30:
+                                      `value[x, y] = max(v_cur, v_prev) + value[x, y]`).  Takes the
+                                      barrier-per-frame kernel (the fast one never materialises Q); the
+                                      score pointer must be writable                                 */
 
 /* bits of the device status word (aligner_maxpath_read_status) */
 #define ALIGNER_ST_BAD_LENGTHS  1  /* some utterance had t_x < 1 or t_x > t_y
@@ -168,11 +173,13 @@ int aligner_debug_set_option(const char *name, int value);
 /*
  * Host-buffer form with exactly maximum_path_c's contract (core.pyx:40):
  * paths[B,Tx,Ty] int32 receives the path (fully overwritten), values[B,Tx,Ty]
- * fp32 is read (it is NOT turned into the running score Q),
- * t_xs/t_ys[B] int32.  Stages through device memory it allocates and frees;
- * blocking.  Returns ALIGNER_EDOM if any t_x < 1 or t_x > t_y.
+ * fp32 holds the scores; with ALIGNER_F_WRITE_Q in `flags` it comes back as the
+ * running score Q inside every utterance's band, bit for bit what the reference
+ * leaves there (without the flag it is only read), t_xs/t_ys[B] int32.  Stages
+ * through device memory it allocates and frees; blocking.  Returns ALIGNER_EDOM
+ * if any t_x < 1 or t_x > t_y.
  */
-int aligner_maxpath_host_f32(int32_t *paths, const float *values,
+int aligner_maxpath_host_f32(int32_t *paths, float *values,
                              const int32_t *t_xs, const int32_t *t_ys,
                              int B, int Tx, int Ty, float max_neg_val, int flags);
 

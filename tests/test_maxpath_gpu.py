@@ -315,13 +315,43 @@ def test_sixteen_bit_scores_read_directly(appendix_a, dev, dt):
 
 
 def test_maximum_path_c_numpy_boundary(kats, dev):
-    """core.pyx:40 signature on host buffers, through aligner_maxpath_host_f32."""
+    """core.pyx:40 signature on host buffers, through aligner_maxpath_host_f32: the path AND the scores the
+    reference leaves behind -- `values` comes back as the running score Q inside the band (core.pyx:30), bit for bit
+    against the real reference's own mutated buffers; write_q=False leaves it untouched."""
     import aligner_amd
-    for c in kats[:20]:
+    checked_q = 0
+    for c in kats:
+        ok = bool(np.all((c["tx"] >= 1) & (c["tx"] <= c["ty"])))          # (the rest: test_degenerate_lengths)
+        if not ok:
+            continue
         p = np.zeros(c["value"].shape, np.int32)
         v = c["value"].copy()
         aligner_amd.maximum_path_c(p, v, c["tx"].copy(), c["ty"].copy(), c["neg"])
         assert np.array_equal(p, c["path"].astype(np.int32)), c["tag"]
+        if c["q"].size:
+            # every finite or infinite score bit for bit; NaNs in the same cells (their sign and payload are the
+            # adding hardware's: x86 makes 0xFFC00000 of inf - inf, gfx950 0x7FC00000 -- not the algorithm's)
+            nan = np.isnan(c["q"])
+            assert np.array_equal(np.isnan(v), nan), c["tag"]
+            assert np.array_equal(v.view(np.uint32)[~nan], c["q"].view(np.uint32)[~nan]), c["tag"]
+            checked_q += 1
+        p2 = np.zeros(c["value"].shape, np.int32)
+        v2 = c["value"].copy()
+        aligner_amd.maximum_path_c(p2, v2, c["tx"].copy(), c["ty"].copy(), c["neg"], write_q=False)
+        assert np.array_equal(p2, p) and np.array_equal(v2.view(np.uint32), c["value"].view(np.uint32)), c["tag"]
+    assert checked_q >= 30
+    # a full-size batch: Q against the C restatement (itself pinned to those fixtures)
+    from oracle import maxpath_oracle as O
+    rng = np.random.default_rng(3)
+    B, Tx, Ty = 3, 300, 900
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    ty = np.array([Ty, 700, 300], np.int32)
+    tx = np.array([Tx, 120, 300], np.int32)
+    want_p, want_q = np.zeros(v.shape, np.int32), v.copy()
+    O.maximum_path_c(want_p, want_q, tx, ty, -1e9)
+    p = np.zeros(v.shape, np.int32)
+    aligner_amd.maximum_path_c(p, v, tx, ty, -1e9)
+    assert np.array_equal(p, want_p) and np.array_equal(v.view(np.uint32), want_q.view(np.uint32))
     with pytest.raises(ValueError):
         aligner_amd.maximum_path_c(np.zeros((1, 4, 3), np.int32), np.zeros((1, 4, 3), np.float32),
                                    np.array([4], np.int32), np.array([3], np.int32))
