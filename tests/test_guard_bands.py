@@ -170,3 +170,28 @@ def test_fused_kernel_writes_stay_inside_their_buffers(dev, B, C, Tx, Ty):
     for name, f in (("workspace", ws), ("logp", logp), ("tok", tok), ("durations", dur)):
         assert f.intact(), f"{name}: the fused kernel wrote outside its buffer"
     assert bool((dur.view(torch.int32, (B, Tx)).sum(1) == t_y).all())
+
+
+@pytest.mark.parametrize("B,Tx,Ty", [(3, 7, 13), (2, 127, 1000), (2, 505, 700)])
+def test_running_scores_written_in_place_stay_inside_the_score_block(dev, B, Tx, Ty):
+    """ALIGNER_F_WRITE_Q on device pointers: the score block itself is written (core.pyx:30), and nothing around it."""
+    lib = _lib.load()
+    from oracle import maxpath_oracle as O
+    rng = np.random.default_rng(Tx + Ty)
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    ty = rng.integers(max(Tx, Ty // 2), Ty + 1, B).astype(np.int32)
+    tx = np.array([rng.integers(1, Tx + 1) for _ in ty], np.int32)
+    tx[0], ty[0] = Tx, Ty
+    val = Fenced(B * Tx * Ty * 4, dev)
+    val.view(torch.float32, (B, Tx, Ty)).copy_(torch.from_numpy(v))
+    d_tx, d_ty = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    wsb = lib.aligner_maxpath_workspace_bytes(B, Tx, Ty)
+    ws, path = Fenced(wsb, dev), Fenced(B * Tx * Ty * 4, dev)
+    _lib.check(lib.aligner_maxpath_f32(val.ptr, None, 0, d_tx.data_ptr(), d_ty.data_ptr(), path.ptr, _lib.DT_I32, None, None,
+                                       ws.ptr, wsb, B, Tx, Ty, -1e9, _lib.F_WRITE_Q, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert val.intact() and ws.intact() and path.intact()
+    want_p, want_q = np.zeros(v.shape, np.int32), v.copy()
+    O.maximum_path_c(want_p, want_q, tx, ty, -1e9)
+    assert np.array_equal(path.view(torch.int32, (B, Tx, Ty)).cpu().numpy(), want_p)
+    assert np.array_equal(val.view(torch.float32, (B, Tx, Ty)).cpu().numpy().view(np.uint32), want_q.view(np.uint32))
