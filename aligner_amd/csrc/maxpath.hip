@@ -40,6 +40,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "aligner_amd.h"
 #include "common.h"
@@ -767,12 +768,19 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             const int brow = (lane == 0) ? p.ROWS - 1 : row;            // decision word column (ghost lane: padding)
             unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + brow;
 
-            for (int i = 0; i < t_lo + w + 1; ++i) PHASE_BARRIER();
-            for (int t = t_lo; t <= t_hi; ++t) {
-                // one ds_read_b128 per 4 frames; the padded row stride (9 x 16 B) makes the 16-lane
-                // groups of a b128 read hit 16 different 16-byte slots: conflict-free
-                const lds_f32x4 *src = (const lds_f32x4 *)((lane == 0) ? (myring + (t & (RING_T - 1)) * RING_LD)
-                                                                         : (mytiles + (t & 1) * 64 * TILE_LD));
+            // One tile.  What does not change from tile to tile is decided outside the loop (a uniform branch costs a
+            // wave about 20 cycles taken or not, and the loop had a dozen): PUB = this wave's last row feeds another
+            // wave; DG = the tile may touch the diagonal (only a wave's first one to three tiles can); BM = where the
+            // decision words go (0 workspace, 1 LDS, 2 LDS + the P table).
+            typedef __attribute__((address_space(3))) const float lds_cf32;
+            lds_cf32 *tile_l = (lds_cf32 *)mytiles, *ring_l = (lds_cf32 *)myring;
+            auto tile = [&](auto PUB, auto DG, auto BM, int t) {
+                constexpr bool pub = decltype(PUB)::value;
+                constexpr int bm = decltype(BM)::value;
+                // one ds_read_b128 per 4 frames; the padded row stride (9 x 16 B) makes the 16-lane groups of a b128
+                // read hit 16 different 16-byte slots: conflict-free.  Lane 0 reads the row above from the ring.
+                lds_cf32 *tl = tile_l + (t & 1) * 64 * TILE_LD, *rg = ring_l + (t & (RING_T - 1)) * RING_LD;
+                const lds_f32x4 *src = (const lds_f32x4 *)((lane == 0) ? rg : tl);
                 float4 vv[8];
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
@@ -780,20 +788,16 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     vv[g] = make_float4(r.x, r.y, r.z, r.w);
                 }
                 const int y0 = t * TC;
-                const bool diag = (y0 <= RPW * w + RPW - 1) && (y0 + TC - 1 >= RPW * w);
                 const int rrel = row - y0;
-                if (diag) {
-                    if (publish) sweep_tile_fast<true, true>(q, m, bits, coll, vv, rrel, p.neg);
-                    else         sweep_tile_fast<false, true>(q, m, bits, coll, vv, rrel, p.neg);
-                } else {
-                    if (publish) sweep_tile_fast<true, false>(q, m, bits, coll, vv, rrel, p.neg);
-                    else         sweep_tile_fast<false, false>(q, m, bits, coll, vv, rrel, p.neg);
-                }
+                if (decltype(DG)::value && (y0 <= RPW * w + RPW - 1) && (y0 + TC - 1 >= RPW * w))
+                    sweep_tile_fast<pub, true>(q, m, bits, coll, vv, rrel, p.neg);
+                else
+                    sweep_tile_fast<pub, false>(q, m, bits, coll, vv, rrel, p.neg);
                 // unmasked stores: lanes >= 32 hit the slot's padding, the ghost lane a padding column
-                if (publish) outring[(t & (RING_T - 1)) * RING_LD + lane] = __builtin_bit_cast(float, coll);
-                if (p.bits_in_lds) {
+                if (pub) outring[(t & (RING_T - 1)) * RING_LD + lane] = __builtin_bit_cast(float, coll);
+                if (bm >= 1) {
                     bitsL[t * RPB + brow] = bits;                              // frame 32t+c <-> bit 31-c
-                    if (p.lds_prev_off) {
+                    if (bm == 2) {
                         // P[t][row]: where the backtrack goes from a token of this row still running at the
                         // end of tile t = (last frame <= 32t+31 with a decision bit) - 1  (walk_chunk_prev)
                         pprev = bits ? (TC * t + TC - 2 - __builtin_ctz(bits)) : pprev;
@@ -804,6 +808,28 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                 }
                 bits = 0u;
                 PHASE_BARRIER();
+            };
+            // the tiles the diagonal crosses come first (rows 63w .. 63w+62 meet frames of the same numbers)
+            const int t_dend = (RPW * w + RPW - 1) / TC;
+            auto run = [&](auto PUB, auto BM) {
+                int t = t_lo;
+                for (; t <= t_hi && t <= t_dend; ++t) tile(PUB, std::integral_constant<bool, true>(), BM, t);
+                for (; t <= t_hi; ++t) tile(PUB, std::integral_constant<bool, false>(), BM, t);
+            };
+            for (int i = 0; i < t_lo + w + 1; ++i) PHASE_BARRIER();
+            {
+                std::integral_constant<bool, true> yes;
+                std::integral_constant<bool, false> no;
+                const int bmode = p.bits_in_lds ? (p.lds_prev_off ? 2 : 1) : 0;
+                if (publish) {
+                    if (bmode == 2) run(yes, std::integral_constant<int, 2>());
+                    else if (bmode == 1) run(yes, std::integral_constant<int, 1>());
+                    else run(yes, std::integral_constant<int, 0>());
+                } else {
+                    if (bmode == 2) run(no, std::integral_constant<int, 2>());
+                    else if (bmode == 1) run(no, std::integral_constant<int, 1>());
+                    else run(no, std::integral_constant<int, 0>());
+                }
             }
             for (int i = 0; i < ntb + NW - w - t_hi - 2; ++i) PHASE_BARRIER();
         } else {
