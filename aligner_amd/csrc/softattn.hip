@@ -551,51 +551,37 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
         const float c0 = -lse2 * LN2_F;
         float m2 = NEG_INF_F;
         const bool plain = !p.prior && !p.soft;                              // uniform
-        if (col_ok && plain && !p.out16) {
-            // the common case, kept free of loop-carried state: a uniform row base (scalar) plus one
-            // 32-bit lane offset per store
-            float *const out_b = p.logp + (size_t)b * p.Tx * p.Ty;
-            const int lane_off32 = 4 * half * p.Ty + col;
+        if (plain) {
+            // the common case: every store unconditional.  The utterance's [Tx,Ty] block is a buffer resource, so a
+            // store past it (the text rows >= Tx of the last tile) is dropped by the hardware; a lane whose frame does
+            // not exist (col >= Ty) carries an offset beyond any block.  No bounds test, no branch per tile or per
+            // store (a uniform branch costs a wave ~20 cycles, an exec-masked store a save / branch / restore):
+            // a uniform row offset (scalar, a compile-time multiple of Ty) plus one 32-bit lane offset.
+            const unsigned esz = p.out16 ? 2u : 4u;
+            const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<unsigned char *>(p.logp) + (size_t)b * p.Tx * p.Ty * esz, 0,
+                (unsigned)p.Tx * (unsigned)p.Ty * esz, 0x00020000);
+            const unsigned lane_byte = col_ok ? (unsigned)(4 * half * p.Ty + col) * esz : 0x80000000u;
+            const unsigned row_bytes = (unsigned)p.Ty * esz;
+            if (!p.out16) {                                                  // uniform, once
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
-                if (32 * r < p.Tx) {                                         // uniform
-                    if (32 * r + 32 <= p.Tx) {                               // uniform: a full tile
+                for (int r = 0; r < G; ++r)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                            out_b[(size_t)iu * p.Ty + lane_off32] = fmaf(lg[r][e], LN2_F, c0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                            if (i_lane + iu < p.Tx) out_b[(size_t)iu * p.Ty + lane_off32] = fmaf(lg[r][e], LN2_F, c0);
-                        }
+                    for (int e = 0; e < 16; ++e) {
+                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaf(lg[r][e], LN2_F, c0)), out_rs,
+                                                              lane_byte, (unsigned)iu * row_bytes, 0);
                     }
-                }
-            }
-        }
-        if (col_ok && plain && p.out16) {
-            // the same with 2-byte stores (bf16 log-probs: half the write traffic)
-            __bf16 *const out_b = reinterpret_cast<__bf16 *>(p.logp) + (size_t)b * p.Tx * p.Ty;
-            const int lane_off32 = 4 * half * p.Ty + col;
+            } else {                                                         // bf16 log-probs: half the write traffic
 #pragma unroll
-            for (int r = 0; r < G; ++r) {
-                if (32 * r < p.Tx) {                                         // uniform
-                    if (32 * r + 32 <= p.Tx) {                               // uniform: a full tile
+                for (int r = 0; r < G; ++r)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                            out_b[(size_t)iu * p.Ty + lane_off32] = (__bf16)fmaf(lg[r][e], LN2_F, c0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) {
-                            const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
-                            if (i_lane + iu < p.Tx) out_b[(size_t)iu * p.Ty + lane_off32] = (__bf16)fmaf(lg[r][e], LN2_F, c0);
-                        }
+                    for (int e = 0; e < 16; ++e) {
+                        const int iu = 32 * r + (e & 3) + 8 * (e >> 2);
+                        const __bf16 hv = (__bf16)fmaf(lg[r][e], LN2_F, c0);
+                        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), out_rs, lane_byte,
+                                                              (unsigned)iu * row_bytes, 0);
                     }
-                }
             }
         }
         if (col_ok && !plain) {
@@ -1497,6 +1483,8 @@ int aligner_softattn(const float *keys, const float *queries, const int32_t *t_x
     if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
     if (C > 256) return fail(ALIGNER_EDOM, "C=%d exceeds 256 attention channels", C);
     if (B > 65535) return fail(ALIGNER_EDOM, "B=%d too large", B);
+    if ((size_t)Tx * (size_t)Ty >= (1ull << 29))          // an utterance's block is one buffer resource (32-bit offsets)
+        return fail(ALIGNER_EDOM, "Tx*Ty=%zu exceeds 2^29", (size_t)Tx * Ty);
     if (B == 0) return ALIGNER_OK;
     const SaLayout L = sa_layout(B, C, Tx);
     if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
