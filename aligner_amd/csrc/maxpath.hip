@@ -698,7 +698,7 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
                     bitsL[t * RPB + slot] = wv;
                     if (p.lds_prev_off) {
                         pprev = wv ? (TC * t + TC - 2 - __builtin_ctz(wv)) : pprev;
-                        prevL[t * RPB + slot] = (unsigned)pprev;
+                        prevL[(t + 1) * RPB + slot] = (unsigned)pprev;        // (slot t + 1: the walk indexes P with e's tile)
                     }
                 } else {
                     gw[(size_t)t * p.ROWS] = wv;
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                         // P[t][row]: where the backtrack goes from a token of this row still running at the
                         // end of tile t = (last frame <= 32t+31 with a decision bit) - 1  (walk_chunk_prev)
                         pprev = bits ? (TC * t + TC - 2 - __builtin_ctz(bits)) : pprev;
-                        prevL[t * RPB + brow] = (unsigned)pprev;
+                        prevL[(t + 1) * RPB + brow] = (unsigned)pprev;        // (kept one tile up: slot t + 1)
                     }
                 } else {
                     gbits[(size_t)t * p.ROWS] = bits;
@@ -1231,9 +1231,10 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                 lds = fwd + bits_lds;
                 // room for the P table as well (and a walk with (W, P) in 128 + 64 VGPRs: NW <= 4): the
                 // backtrack's steps then cannot fail (walk_chunk_prev)
-                if (NW <= 4 && lds + bits_lds <= lds_max && !(flags & ALIGNER_F_NO_PREV_TABLE)) {
+                const size_t prev_lds = bits_lds + (size_t)row_pitch(L.ROWS) * 4;     // NT + 1 slots: tile t's entry in slot t + 1
+                if (NW <= 4 && L.NT < 64 && lds + prev_lds <= lds_max && !(flags & ALIGNER_F_NO_PREV_TABLE)) {
                     p.lds_prev_off = (int)lds;
-                    lds += bits_lds;
+                    lds += prev_lds;
                 }
             } else {
                 p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
