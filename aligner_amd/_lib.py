@@ -22,6 +22,7 @@ F_COMPAT_TXGTTY = 2
 F_FORCE_GENERIC = 4
 F_NO_PREV_TABLE = 16
 F_WRITE_Q = 64
+F_STREAM_PATH = 128
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2
@@ -49,6 +50,7 @@ SIGNATURES = {
     "aligner_maxpath_forward_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                          _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "aligner_maxpath_expand_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "aligner_maxpath_read_status": (_i, [_vp, _vp, _vp]),
     "aligner_debug_set_stamps": (None, [_vp]),
     "aligner_debug_set_option": (_i, [_c.c_char_p, _i]),

@@ -1013,7 +1013,10 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
 // starts -> dense 0/1 path in the caller's dtype (the reference's return value,
 // __init__.py:21).  Pure streaming store: path[b,x,y] = starts[x] <= y < starts[x+1].
 // --------------------------------------------------------------------------
-template <typename T, bool VEC>
+// STREAM: the dense path leaves with non-temporal stores -- 51 MB that nothing on the GPU reads back soon do not push
+// the score tensor of the batches in flight out of the caches (bench.py with three batches in flight: 39.9 -> 33.8 us
+// per step; alone the kernel is slower, 9.2 -> 11.6 us, so it is the caller's choice: ALIGNER_F_STREAM_PATH)
+template <typename T, bool VEC, bool STREAM>
 __global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ starts, T *__restrict__ path,
                                                       int Tx, int Ty, int rows_per_block, T one) {
     const int b = blockIdx.z;
@@ -1031,7 +1034,14 @@ __global__ __launch_bounds__(256) void expand_kernel(const int *__restrict__ sta
 #pragma unroll
         for (int i = 0; i < 4; ++i) o.v[i] = (y0 + i >= s && y0 + i < e) ? one : T(0);
         if (VEC) {
-            *reinterpret_cast<Vec4 *>(dst) = o;
+            if (STREAM) {
+                typedef T TV __attribute__((ext_vector_type(4)));
+                TV ov;
+                ov.x = o.v[0]; ov.y = o.v[1]; ov.z = o.v[2]; ov.w = o.v[3];
+                __builtin_nontemporal_store(ov, reinterpret_cast<TV *>(dst));
+            } else {
+                *reinterpret_cast<Vec4 *>(dst) = o;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1271,28 +1281,30 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
 }
 
 template <typename T>
-static int launch_expand(const int *starts, void *path, int B, int Tx, int Ty, T one, hipStream_t s) {
+static int launch_expand(const int *starts, void *path, int B, int Tx, int Ty, T one, bool stream_path, hipStream_t s) {
     const int rpb = 8;
     dim3 grid((Ty + 1023) / 1024, (Tx + rpb - 1) / rpb, B), block(256);
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) % (sizeof(T) * 4)) == 0);
-    if (vec)
-        hipLaunchKernelGGL((expand_kernel<T, true>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
+    if (vec && stream_path)
+        hipLaunchKernelGGL((expand_kernel<T, true, true>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
+    else if (vec)
+        hipLaunchKernelGGL((expand_kernel<T, true, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
     else
-        hipLaunchKernelGGL((expand_kernel<T, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
+        hipLaunchKernelGGL((expand_kernel<T, false, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
 
-static int expand_impl(const int *starts, void *path, int path_dtype, int B, int Tx, int Ty, hipStream_t s) {
+static int expand_impl(const int *starts, void *path, int path_dtype, int B, int Tx, int Ty, bool stream_path, hipStream_t s) {
     if (B > 65535 || (Tx + 7) / 8 > 65535) return fail(ALIGNER_EDOM, "grid too large");
     switch (path_dtype) {
-        case ALIGNER_DT_F32: return launch_expand<float>(starts, path, B, Tx, Ty, 1.0f, s);
-        case ALIGNER_DT_F64: return launch_expand<double>(starts, path, B, Tx, Ty, 1.0, s);
-        case ALIGNER_DT_I32: return launch_expand<int32_t>(starts, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_I64: return launch_expand<int64_t>(starts, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_U8:  return launch_expand<uint8_t>(starts, path, B, Tx, Ty, 1, s);
-        case ALIGNER_DT_F16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3C00, s);
-        case ALIGNER_DT_BF16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3F80, s);
+        case ALIGNER_DT_F32: return launch_expand<float>(starts, path, B, Tx, Ty, 1.0f, stream_path, s);
+        case ALIGNER_DT_F64: return launch_expand<double>(starts, path, B, Tx, Ty, 1.0, stream_path, s);
+        case ALIGNER_DT_I32: return launch_expand<int32_t>(starts, path, B, Tx, Ty, 1, stream_path, s);
+        case ALIGNER_DT_I64: return launch_expand<int64_t>(starts, path, B, Tx, Ty, 1, stream_path, s);
+        case ALIGNER_DT_U8:  return launch_expand<uint8_t>(starts, path, B, Tx, Ty, 1, stream_path, s);
+        case ALIGNER_DT_F16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3C00, stream_path, s);
+        case ALIGNER_DT_BF16: return launch_expand<uint16_t>(starts, path, B, Tx, Ty, 0x3F80, stream_path, s);
         default: return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
     }
 }
@@ -1358,14 +1370,20 @@ int aligner_maxpath_forward_f32(const float *value, const void *mask, int mask_d
                         max_neg_val, flags, static_cast<hipStream_t>(stream));
 }
 
-int aligner_maxpath_expand(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty,
-                           void *stream) {
+int aligner_maxpath_expand_ex(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty, int flags,
+                              void *stream) {
     if (!ws || !path) return fail(ALIGNER_EINVAL, "null pointer");
     if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
     if (B == 0) return ALIGNER_OK;
     const WsLayout L = ws_layout(B, Tx, Ty);
     const int *starts = reinterpret_cast<const int *>(static_cast<const unsigned char *>(ws) + L.starts_off);
-    return expand_impl(starts, path, path_dtype, B, Tx, Ty, static_cast<hipStream_t>(stream));
+    return expand_impl(starts, path, path_dtype, B, Tx, Ty, (flags & ALIGNER_F_STREAM_PATH) != 0,
+                       static_cast<hipStream_t>(stream));
+}
+
+int aligner_maxpath_expand(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty,
+                           void *stream) {
+    return aligner_maxpath_expand_ex(ws, path, path_dtype, B, Tx, Ty, 0, stream);
 }
 
 int aligner_maxpath(const void *value, int value_dtype, const void *mask, int mask_dtype, const int32_t *t_xs,
@@ -1377,7 +1395,7 @@ int aligner_maxpath(const void *value, int value_dtype, const void *mask, int ma
     int rc = forward_impl(value, value_dtype, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
                           max_neg_val, flags, static_cast<hipStream_t>(stream));
     if (rc || !path_out || B == 0) return rc;
-    return aligner_maxpath_expand(ws, path_out, path_dtype, B, Tx, Ty, stream);
+    return aligner_maxpath_expand_ex(ws, path_out, path_dtype, B, Tx, Ty, flags, stream);
 }
 
 int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, const int32_t *t_xs,

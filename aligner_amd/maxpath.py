@@ -61,7 +61,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           want_path: bool = True, path_dtype: Optional[torch.dtype] = None,
           want_tok: bool = False, want_durations: bool = True,
           max_neg_val: float = -1e9, compat_tx_gt_ty: bool = False,
-          force_generic: bool = False, no_prev_table: bool = False,
+          force_generic: bool = False, no_prev_table: bool = False, stream_path: bool = False,
           out_path: Optional[torch.Tensor] = None) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
@@ -70,6 +70,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
     lengths either as int32 vectors t_x/t_y [B] or derived from `mask`
     (__init__.py:18-19).  With strict_mask the scores are first multiplied by the
     mask element-wise (__init__.py:11).  Asynchronous on the current stream.
+    stream_path: write the dense path with non-temporal stores (ALIGNER_F_STREAM_PATH: worth it when other batches
+    are in flight on the GPU and nothing reads the path back at once).
     """
     if value.dim() != 3:
         raise ValueError(f"value must be [b, t_x, t_y], got {tuple(value.shape)}")
@@ -135,7 +137,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
             flags = (_lib.F_STRICT_MASK if strict_mask else 0) | \
                     (_lib.F_COMPAT_TXGTTY if compat_tx_gt_ty else 0) | \
                     (_lib.F_FORCE_GENERIC if force_generic else 0) | \
-                    (_lib.F_NO_PREV_TABLE if no_prev_table else 0)
+                    (_lib.F_NO_PREV_TABLE if no_prev_table else 0) | \
+                    (_lib.F_STREAM_PATH if stream_path else 0)
             _lib.check(lib.aligner_maxpath(
                 v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
                 ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))

@@ -41,8 +41,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 class Step:
     """One pass of the hot path through the C ABI with preallocated buffers."""
 
-    def __init__(self, dev: torch.device, seed: int, use_graph: bool):
+    def __init__(self, dev: torch.device, seed: int, use_graph: bool, stream_path: bool = False):
         self.dev = dev
+        # ALIGNER_F_STREAM_PATH: non-temporal stores for the dense path (pays with several batches in flight)
+        self.expand_flags = _lib.F_STREAM_PATH if stream_path else 0
         self.lib = _lib.load()
         g = torch.Generator().manual_seed(seed)
         self.keys = torch.randn(B, C_ATT, TX, generator=g).to(dev)       # encoded text  [B,C,Tx]
@@ -78,8 +80,8 @@ class Step:
                                                         self.stream()))
 
     def expand(self):
-        _lib.check(self.lib.aligner_maxpath_expand(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
-                                                   self.stream()))
+        _lib.check(self.lib.aligner_maxpath_expand_ex(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
+                                                      self.expand_flags, self.stream()))
 
     def eager(self):
         self.softattn()
@@ -351,6 +353,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repeats", dest="repeats", action="store_false",
                     help="skip the four extra timed regions (spread) and the one-batch-in-flight figure")
+    ap.add_argument("--no-stream-path", action="store_true", help="ordinary stores for the dense path in every run")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
@@ -394,7 +397,12 @@ def main():
     # S independent batches in flight: step i runs on stream i % S with its own buffers, so the
     # latency-bound DP of one batch (64 of 256 CUs) overlaps the bandwidth-bound kernels of the next
     nstreams = max(1, args.streams)
-    steps = [Step(dev, seed=1234 + 17 * rank + 1000 * i, use_graph=not args.no_graph) for i in range(nstreams)]
+    # the dense path is an output nothing on the GPU reads back: with several batches in flight it is written with
+    # non-temporal stores (ALIGNER_F_STREAM_PATH), so that it does not push the batches' score tensors out of the
+    # caches; one batch at a time is faster with ordinary stores, and the serial figure is taken that way
+    stream_path = nstreams > 1 and not args.no_stream_path
+    steps = [Step(dev, seed=1234 + 17 * rank + 1000 * i, use_graph=not args.no_graph, stream_path=stream_path)
+             for i in range(nstreams)]
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     for st, strm in zip(steps, streams):
         with torch.cuda.stream(strm):
@@ -476,8 +484,14 @@ def main():
     # strictly serial steps (one batch in flight: what a training step that waits for its alignment sees)
     serial_elapsed = None
     if dist is None and args.repeats:
+        if stream_path:                                # one batch at a time: ordinary path stores (see above)
+            steps[0].expand_flags = 0
+            steps[0].capture()
         run(min(args.warmup, 10), 1)
         serial_elapsed = float(np.median([timed(args.steps, 1) for _ in range(3)]))
+        if stream_path:
+            steps[0].expand_flags = _lib.F_STREAM_PATH
+            steps[0].capture()
 
     # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
     for st in steps:
@@ -546,6 +560,8 @@ def main():
                        "batch_per_gpu": B, "t_text": TX, "t_mel": TY, "c_att": C_ATT,
                        "launch": "hipGraph" if step.graph is not None else "eager",
                        "batches_in_flight": nstreams,
+                       "path_stores": ("non-temporal (ALIGNER_F_STREAM_PATH) with the batches in flight, ordinary in the "
+                                       "serial figure" if stream_path else "ordinary"),
                        "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
                                                                f"{ge} steps" if n > 1 else "")},
             "roofline": roofline,

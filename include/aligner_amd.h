@@ -64,6 +64,11 @@ extern "C" {
 
 #define ALIGNER_F_NO_PREV_TABLE 16 /* testing: do not keep the backtrack's second LDS table (the walk then
                                       takes the flag-and-retry steps it uses for long utterances)   */
+#define ALIGNER_F_STREAM_PATH  128 /* the dense path is written with non-temporal stores: a large output that
+                                      nothing on the GPU reads back soon then does not displace the score
+                                      tensors of other batches in flight from the caches (three batches in
+                                      flight: 39.9 -> 33.8 us per step at [64,200,1000]; one batch alone is
+                                      2 us slower).  The caller's choice; off by default                */
 #define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside
                                       the band, in place, exactly as the reference does (core.pyx:18,30:
                                       `value[x, y] = max(v_cur, v_prev) + value[x, y]`).  Takes the
@@ -155,6 +160,8 @@ int aligner_maxpath_forward_f32(const float *value_dev,
                                 float max_neg_val, int flags, void *stream);
 int aligner_maxpath_expand(const void *workspace_dev, void *path_out_dev, int path_dtype,
                            int B, int Tx, int Ty, void *stream);
+int aligner_maxpath_expand_ex(const void *workspace_dev, void *path_out_dev, int path_dtype,
+                           int B, int Tx, int Ty, int flags /* ALIGNER_F_STREAM_PATH */, void *stream);
 
 /* Blocking read-and-clear of the workspace's status word (ALIGNER_ST_* bits).  The
  * word is sticky: kernels only OR bits into it, so the first 256 bytes of a fresh

@@ -52,7 +52,7 @@ SHAPES = [(1, 1, 1), (3, 7, 13), (2, 63, 64), (4, 64, 257), (2, 127, 1000), (3, 
 
 
 @pytest.mark.parametrize("B,Tx,Ty", SHAPES)
-@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE])
+@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE, _lib.F_STREAM_PATH])
 def test_alignment_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, flags):
     lib = _lib.load()
     rng = np.random.default_rng(B * 1000 + Tx + Ty)

@@ -45,7 +45,8 @@ def _check_consistency(path, tok, dur, tx, ty):
             assert np.array_equal(path[b].argmax(0)[:ty[b]], tok[b, :ty[b]])
 
 
-KERNELS = {"wide": {}, "wide_retry_walk": {"no_prev_table": True}, "generic": {"force_generic": True}}
+KERNELS = {"wide": {}, "wide_retry_walk": {"no_prev_table": True}, "generic": {"force_generic": True},
+           "wide_streamed_path": {"stream_path": True}}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -411,6 +412,12 @@ def test_expand_dtypes(dev, dt):
                           path_dtype=dt)
     assert r.path.dtype == dt
     assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), want)
+    # the same through the non-temporal stores of ALIGNER_F_STREAM_PATH (16-byte-aligned rows: Ty = 52)
+    v4 = synth.synth_value(3, 17, 52, 98)
+    ty4 = np.array([52, 33, 9], np.int32)
+    r = aligner_amd.align(torch.from_numpy(v4).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty4).to(dev),
+                          path_dtype=dt, stream_path=True)
+    assert r.path.dtype == dt and np.array_equal(r.path.to(torch.int32).cpu().numpy(), _oracle_path(v4, tx, ty4))
     # odd Ty exercises the unaligned (scalar) load/store paths
     v = synth.synth_value(2, 9, 37, 5)
     r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.tensor([9, 3], dtype=torch.int32, device=dev),
