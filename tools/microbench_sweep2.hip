@@ -85,7 +85,7 @@ int main() {
     float *d_out; long long *d_cyc;
     CK(hipMalloc(&d_out, 1 << 22)); CK(hipMalloc(&d_cyc, 1 << 16));
     const int ntiles = 2000;
-    const char *names[8] = {"kernel NOPUB (e64, late addc)", "kernel PUB", "vcc forms", "chain only + s_nop 1", "chain + 2 plain fillers",
+    const char *names[8] = {"kernel NOPUB (current .inc)   ", "kernel PUB", "vcc forms", "chain only + s_nop 1", "chain + 2 plain fillers",
                             "vcc forms, no DPP", "e64 same frame", "kernel DIAG_PUB"};
     const int wv[4] = {1, 4, 8, 16};
     for (int wi = 0; wi < 4; ++wi) {
