@@ -296,20 +296,17 @@ __host__ __device__ constexpr int row_pitch(int ROWS) { return ROWS + 4; }   // 
 // One chunk of fast steps: see maxpath_walk_asm.inc (generated by tools/gen_walk_asm.py).  `lds_addr` = this
 // lane's LDS byte address of (window tile = lane, row 64c); rows kent .. 0 of the chunk are walked.
 template <bool WINDOW>
-__device__ __forceinline__ void walk_chunk_fast(unsigned lds_addr, int kent, int &e, int &flag, int &startv, int jb,
-                                                int ntwm1) {
+__device__ __forceinline__ void walk_chunk_fast(unsigned lds_addr, int kent, int &e, int &flag, int &startv) {
     int je, jm, t, k;
     // (no-ops on values the compiler already knows to be uniform; they keep every "s" operand provably scalar)
     e = __builtin_amdgcn_readfirstlane(e);
     flag = __builtin_amdgcn_readfirstlane(flag);
     const int skip = __builtin_amdgcn_readfirstlane(63 - kent);
-    jb = __builtin_amdgcn_readfirstlane(jb);
-    ntwm1 = __builtin_amdgcn_readfirstlane(ntwm1);
     if (WINDOW)
         asm volatile(ALIGNER_WALK64_W
                      : [e] "+s"(e), [flag] "+s"(flag), [sv] "+v"(startv), [je] "=&s"(je), [jm] "=&s"(jm), [t] "=&s"(t),
                        [k] "=&s"(k)
-                     : [addr] "v"(lds_addr), [skip] "s"(skip), [jb] "s"(jb), [ntwm1] "s"(ntwm1)
+                     : [addr] "v"(lds_addr), [skip] "s"(skip)
                      : ALIGNER_WALK64_CLOBBERS, "memory");
     else
         asm volatile(ALIGNER_WALK64
@@ -369,34 +366,49 @@ __device__ __forceinline__ void walk_rows_slow(const unsigned *wrow, int xhi, in
 }
 
 // One chunk of 64 rows (64c .. 64c+63), entered at row x.  Fast steps; if the flag came up, the FIRST row that
-// failed is the highest one whose step did not move e down (a failed step yields e + 1) or whose tiles were not
-// both in the window; everything above it is good.  That row takes the general search (walk_rows_slow) and the
-// fast steps are re-entered right below it.  Leaves x = the next row to walk (64c - 1, or 0 when chunk 0
-// completed: row 0 is never walked, it starts at frame 0 -- the fast steps run over it and its outcome is
-// ignored), or the row to resume at in an earlier window (stop).
+// failed is the highest one whose step did not move e down (a failed step yields e + 1) or (WINDOW) whose e was
+// not past the window's first tile; everything above it is good.  That row takes the general search
+// (walk_rows_slow) and the fast steps are re-entered right below it.  WINDOW: tiles [jb, jb + ntw) with jb > 0; the
+// fast steps run on window-relative frames (maxpath_walk_asm.inc) and their results are shifted back here.  An
+// entry row whose e lies above the window (its token runs on from a later window) takes the general search too.
+// Leaves x = the next row to walk (64c - 1, or 0 when chunk 0 completed: row 0 is never walked, it starts at frame
+// 0 -- the fast steps run over it and its outcome is ignored), or the row to resume at in an earlier window (stop).
 template <bool WINDOW>
 __device__ __forceinline__ void walk_chunk(const unsigned *wrow, int c, int &x, int &e, int &startv, int lane, int jb,
                                            int ntw, int &stop, int *status) {
     typedef __attribute__((address_space(3))) const unsigned lds_cu32;
     const unsigned lds_addr = (unsigned)(unsigned long long)(lds_cu32 *)(wrow + 64 * c);
     const int klo = (c == 0) ? 1 : 0;
+    const int off = WINDOW ? (jb << 5) : 0;
     int kent = x - 64 * c;
     while (kent >= klo) {
+        if ((e >> 5) - jb >= ntw) {                              // only ever the row a window change resumes at
+            x = 64 * c + kent;
+            walk_rows_slow(wrow, x, x, x, e, startv, lane, jb, ntw, stop, status, jb > 0);
+            if (stop) return;
+            --kent;
+            continue;
+        }
+        if (WINDOW && e - off < 32) { x = 64 * c + kent; stop = 1; return; }   // the next window's row
         const int top = kent, e_in = e;
         int flag = 0;
-        walk_chunk_fast<WINDOW>(lds_addr, kent, e, flag, startv, jb, ntw - 1);
+        e -= off;
+        walk_chunk_fast<WINDOW>(lds_addr, kent, e, flag, startv);
+        e += off;
+        if (WINDOW) startv = (lane <= top) ? startv + off : startv;   // (rows it did not reach are walked again)
         if (__builtin_expect(flag >= 0, 1)) break;
         // e entering each row: the step result of the row above it (lane + 1), e_in for the entry row
         int prev = __builtin_amdgcn_update_dpp(0, startv, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
         prev = (lane == top) ? e_in : prev;
         bool bad = startv >= prev;
-        if (WINDOW) bad = bad || (unsigned)((prev >> 5) - jb - 1) >= (unsigned)(ntw - 1);
+        if (WINDOW) bad = bad || prev - off < 32;
         const unsigned long long m = __ballot(bad && lane <= top && lane >= klo);
-        if (m == 0ull) break;                                    // chunk 0: only the (unwalked) row 0 raised it
+        if (m == 0ull) break;                                    // raised by the last row's outcome only: all rows good
         const int kf = 63 - __builtin_clzll(m);                  // first (highest) failed row of the chunk
         e = __builtin_amdgcn_readfirstlane((kf == top) ? e_in : __builtin_amdgcn_readlane(startv, (kf + 1) & 63));
         x = 64 * c + kf;
-        walk_rows_slow(wrow, x, x, x, e, startv, lane, jb, ntw, stop, status, WINDOW);
+        if (WINDOW && e - off < 32) { stop = 1; return; }        // e is in the window's first tile: the next window's row
+        walk_rows_slow(wrow, x, x, x, e, startv, lane, jb, ntw, stop, status, jb > 0);
         if (stop) return;
         kent = kf - 1;
     }
@@ -453,9 +465,11 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
     int e = __builtin_amdgcn_readfirstlane(ty - 1);
     int startv = 0;   // (first frame - 1) of rows 64c..64c+63 of the chunk being walked, one per lane
 
-    const bool single = ntb <= WT;                     // every tile of the utterance in one window
-    for (int jhi = ntb; jhi > 0; jhi -= WT) {
-        const int jb = (jhi - WT > 0) ? (jhi - WT) : 0;
+    // windows of WT tiles from the last one down, each sharing its first tile with the next one's last: a row whose
+    // last frame is in a window's first tile has no tile before it there and is resumed as an ordinary row of the
+    // next window (WT >= 2 whenever the tiles do not fit one window, pick_window)
+    for (int jhi = ntb, jb = 0; jhi > 0; jhi = (jb > 0) ? jb + 1 : 0) {
+        jb = (jhi - WT > 0) ? (jhi - WT) : 0;
         const int ntw = jhi - jb;
         if (!in_lds) {
             __syncthreads();                           // previous window fully consumed
@@ -476,7 +490,7 @@ __device__ __forceinline__ void backtrack_and_store(const MaxpathParams &p, int 
                     walk_chunk_prev((unsigned)(unsigned long long)(lds_cu32 *)(wrow + 64 * c),
                                     (unsigned)(unsigned long long)(lds_cu32 *)(prow + 64 * c), x - 64 * c, e, startv);
                     x = (c == 0) ? 0 : 64 * c - 1;
-                } else if (single) {
+                } else if (jb == 0) {                  // (every tile in one window, or the last of several)
                     walk_chunk<false>(wrow, c, x, e, startv, lane, 0, ntw, stop, p.status);
                 } else {
                     walk_chunk<true>(wrow, c, x, e, startv, lane, jb, ntw, stop, p.status);
@@ -1115,8 +1129,9 @@ static size_t starts_bytes(int Tx) { return (size_t)(((Tx + 1 + 63) / 64) * 64 +
 static size_t walk_bytes(int WT, int ROWS, int Tx) { return starts_bytes(Tx) + (size_t)WT * row_pitch(ROWS) * 4; }
 
 static int pick_window(int NT, int ROWS, int Tx, size_t budget) {
-    int WT = NT < 64 ? NT : 64;
-    while (WT > 1 && walk_bytes(WT, ROWS, Tx) > budget) --WT;
+    int WT = NT < 64 ? NT : 64;                      // (successive windows share a tile: at least two, or all of them)
+    const int least = NT < 2 ? NT : 2;
+    while (WT > least && walk_bytes(WT, ROWS, Tx) > budget) --WT;
     return walk_bytes(WT, ROWS, Tx) <= budget ? WT : 0;
 }
 
