@@ -23,6 +23,8 @@ F_FORCE_GENERIC = 4
 F_NO_PREV_TABLE = 16
 F_WRITE_Q = 64
 F_STREAM_PATH = 128
+F_ONE_CU = 256
+F_TWO_CUS = 512
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2

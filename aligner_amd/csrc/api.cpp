@@ -42,6 +42,19 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes) {
     return e;
 }
 
+int device_cu_count() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    static std::mutex mu;
+    static std::map<int, int> counts;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = counts.find(dev);
+    if (it != counts.end()) return it->second;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 1;
+    counts[dev] = v;
+    return v;
+}
+
 int device_lds_limit() {
     // gfx950 lets one workgroup own the CU's whole 160 KiB LDS; cached per device
     int dev = 0;

@@ -39,6 +39,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes);   // cached per
 
 // LDS bytes one workgroup may own on the current device (160 KiB on gfx950), cached per device
 int device_lds_limit();
+int device_cu_count();                // compute units of the current device (cached per device)
 
 // development aid shared by the kernel files (aligner_debug_set_stamps)
 extern unsigned long long *g_debug_stamps;

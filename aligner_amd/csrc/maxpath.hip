@@ -84,7 +84,9 @@ struct MaxpathParams {
     int flags;
     float *qout;            // ALIGNER_F_WRITE_Q: the running scores Q go back into the score block, as core.pyx:30 (nullable)
     int lds_total;          // bytes of LDS the launch asked for (store_outputs: is there room for its scratch?)
-    unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable)
+    unsigned    *xring;     // two workgroups per utterance: [B][NT][32] boundary row between the halves (workspace, 0xFF-filled)
+    int         *xflag;     // ... [B] first half done (1; 2 = it met a non-finite score), 0xFFFFFFFF until then
+    unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable; [2B] when utterances are split)
     float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
 };
 
@@ -731,21 +733,45 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 #else
 #define PHASE_BARRIER() __syncthreads()
 #endif
-template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT>
+// PAIR: two workgroups -- two CUs -- per utterance (grid 2B: block b takes compute waves 0..NW-1 of utterance b,
+// block B + b waves NW..2NW-1).  A CU's VALU is what a long text (more than 4 x 63 rows: two compute waves per
+// SIMD) is bound by, and a small batch leaves most CUs idle.  The boundary row between the halves goes through
+// global memory: the first half's last compute wave publishes into LDS as if a fifth wave followed, its loader wave
+// forwards those 32 values per tile with agent-scope stores into a ring the host filled with 0xFFFFFFFF (the compute
+// waves' code is the one-workgroup code: any store of theirs that hipcc could not tell from a load made every tile
+// wait for the previous tile's stores), the second half's first loader wave reads them two tiles ahead and polls until no
+// word is the filler (a running score is finite; a NaN with that bit pattern is rewritten before it is stored) --
+// the data is its own flag, nothing waits for a store to complete.  The first half never waits for the second
+// (lower block indices are dispatched first), so the pair cannot deadlock; the second half waits once more, for
+// the first half's decision words (release / acquire on xflag), and then runs the backtrack for the utterance.
+constexpr unsigned XRING_EMPTY = 0xFFFFFFFFu;
+constexpr int XRING_SPIN_LIMIT = 1 << 18;          // polls before giving up for good with ALIGNER_ST_INTERNAL (~0.3 s)
+
+template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT, bool PAIR = false>
 __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
+    static_assert(!PAIR || NW == 4, "the split form is built on the four-wave workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    const int half = PAIR ? (int)(blockIdx.x >= (unsigned)p.B) : 0;
+    const int b = PAIR ? (int)blockIdx.x - half * p.B : (int)blockIdx.x;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
-    if (mode != MODE_NORMAL) { write_degenerate<MASKMODE, VT>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem)); return; }
+    if (mode != MODE_NORMAL) {
+        if (half == 0) write_degenerate<MASKMODE, VT>(p, b, mode, tx, ty, reinterpret_cast<int *>(smem));
+        return;
+    }
+    // paired: this utterance really has rows for the second workgroup; otherwise the first one does everything
+    const bool paired = PAIR && (tx + RPW - 1) / RPW > NW;
+    if (PAIR && half == 1 && !paired) return;
+    const int wbase = NW * half;                                // this workgroup's waves are wbase .. wbase + NW - 1
+    unsigned *xr = PAIR ? p.xring + (size_t)b * p.NT * TC : nullptr;
     ALIGNER_STAMP(0);
     ALIGNER_STAMP(6);
 
     float *tiles = reinterpret_cast<float *>(smem);              // [NW][2][64][TILE_LD]
     float *ring  = tiles + NW * 2 * 64 * TILE_LD;                // [NW][RING_T][RING_LD]: row 63w-1 for wave w
-    int   *flagp = reinterpret_cast<int *>(ring + NW * RING_T * RING_LD);   // [4] non-finite score seen
+    int   *flagp = reinterpret_cast<int *>(ring + (NW + (PAIR ? 1 : 0)) * RING_T * RING_LD);   // [4] non-finite score seen
     unsigned *bitsL = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);   // [NT][ROWS+1] when in LDS
     const int RPB = row_pitch(p.ROWS);
     const int ntb = (ty + TC - 1) / TC;
@@ -760,17 +786,18 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     if (!p.force_exact) {
         // Tiles a wave needs form one contiguous range [t_lo, t_hi] (band of rows 63w..63w+62,
         // core.pyx:18); every wave still takes part in all ntb + NW phase barriers.
-        const int w = (wave < NW) ? wave : wave - NW;
-        const bool active = w < nw_act;
-        const int t_lo = active ? (RPW * w) / TC : 0;
-        int t_hi = active ? (ty - tx + RPW * w + RPW - 1) / TC : -1;
+        const int w = (wave < NW) ? wave : wave - NW;           // index inside the workgroup (LDS buffers, phases)
+        const int gw = wbase + w;                               // index inside the utterance (rows)
+        const bool active = gw < nw_act;
+        const int t_lo = active ? (RPW * gw) / TC : 0;
+        int t_hi = active ? (ty - tx + RPW * gw + RPW - 1) / TC : -1;
         if (t_hi > ntb - 1) t_hi = ntb - 1;
         const int ntiles = t_hi - t_lo + 1;
         if (wave < NW) {
             // ------------------------------ compute wave ------------------------------
-            const int row = RPW * w + lane - 1;                 // lane 0: ghost (row 63w-1)
-            const bool publish = w + 1 < nw_act;
-            float q = (w == 0 && lane == 0) ? 0.0f : p.neg;     // Q[-1,-1] = 0 (core.pyx:24-25)
+            const int row = RPW * gw + lane - 1;                // lane 0: ghost (row 63gw-1)
+            const bool publish = gw + 1 < nw_act;
+            float q = (gw == 0 && lane == 0) ? 0.0f : p.neg;    // Q[-1,-1] = 0 (core.pyx:24-25)
             float m = 0.0f;                                     // lane 0 stays 0 through the asm sweep
             unsigned bits = 0u;
             int coll = 0;
@@ -778,7 +805,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             unsigned *prevL = reinterpret_cast<unsigned *>(smem + p.lds_prev_off);
             const float *mytiles = tiles + w * 2 * 64 * TILE_LD + lane * TILE_LD;
             const float *myring = ring + w * RING_T * RING_LD;
-            float *outring = ring + (publish ? w + 1 : w) * RING_T * RING_LD;
+            float *outring = ring + (publish ? w + 1 : w) * RING_T * RING_LD;   // (PAIR: slot set NW is the loaders' to forward)
             const int brow = (lane == 0) ? p.ROWS - 1 : row;            // decision word column (ghost lane: padding)
             unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS + brow;
 
@@ -803,7 +830,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                 }
                 const int y0 = t * TC;
                 const int rrel = row - y0;
-                if (decltype(DG)::value && (y0 <= RPW * w + RPW - 1) && (y0 + TC - 1 >= RPW * w))
+                if (decltype(DG)::value && (y0 <= RPW * gw + RPW - 1) && (y0 + TC - 1 >= RPW * gw))
                     sweep_tile_fast<pub, true>(q, m, bits, coll, vv, rrel, p.neg);
                 else
                     sweep_tile_fast<pub, false>(q, m, bits, coll, vv, rrel, p.neg);
@@ -824,7 +851,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                 PHASE_BARRIER();
             };
             // the tiles the diagonal crosses come first (rows 63w .. 63w+62 meet frames of the same numbers)
-            const int t_dend = (RPW * w + RPW - 1) / TC;
+            const int t_dend = (RPW * gw + RPW - 1) / TC;
             auto run = [&](auto PUB, auto BM) {
                 int t = t_lo;
                 for (; t <= t_hi && t <= t_dend; ++t) tile(PUB, std::integral_constant<bool, true>(), BM, t);
@@ -850,6 +877,82 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             // ------------------------------ loader wave -------------------------------
             if (active) {
                 float nf = 0.f;                             // maximum |score| seen, NaN-propagating (scan4)
+                // PAIR, first loader wave of the second workgroup: the row above this workgroup's first row comes
+                // from the other CU (see the kernel's header).  Read two tiles ahead like the scores, polled when its
+                // tile is staged, handed to compute wave 0 through the ring slot its ghost lane reads anyway.
+                const bool xsub = PAIR && paired && half == 1 && w == 0;
+                int xt_hi = (ty - tx + RPW * (gw - 1) + RPW - 1) / TC;      // last tile wave gw - 1 publishes
+                if (xt_hi > ntb - 1) xt_hi = ntb - 1;
+                const bool xfw = PAIR && paired && half == 0 && w == NW - 1;   // forwards its compute wave's last row
+                auto xforward = [&](int t) {                                   // tile t is complete in the ring
+                    if constexpr (PAIR) {
+                        if (xfw && t >= t_lo) {
+                            const unsigned cv0 = __builtin_bit_cast(unsigned, ring[NW * RING_T * RING_LD + (t & (RING_T - 1)) * RING_LD + (lane & (TC - 1))]);
+                            const unsigned cv = (cv0 == XRING_EMPTY) ? 0x7FC00000u : cv0;
+                            if (lane < TC) __hip_atomic_store(xr + TC * t + lane, cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                };
+                // after the staging loop: tile t_hi - 1 is in the ring now, t_hi after one more phase (returns the
+                // number of phase barriers it took)
+                auto xforward_tail = [&]() -> int {
+                    if constexpr (PAIR) {
+                        if (xfw) {
+                            xforward(t_hi - 1);
+                            PHASE_BARRIER();
+                            xforward(t_hi);
+                            return 1;
+                        }
+                    }
+                    return 0;
+                };
+                // An agent-scope load is a trip past the L2 (the halves may sit on different XCDs, ~1.3 us): it is issued
+                // XAHEAD tiles early, further than its latency, into a register of its own -- the staging loop is
+                // unrolled XAHEAD times for that (a queue shifted with moves made every tile wait for the load issued
+                // the tile before: a move reads its source).  A read that came too early finds the filler and is
+                // repeated when its tile is staged; that stall drops this workgroup back until its early reads succeed.
+                constexpr int XAHEAD = 2 * DEPTH;
+                constexpr int UNR = PAIR ? XAHEAD : DEPTH;                   // tiles per trip of the staging loop
+                unsigned xq[XAHEAD];
+                bool xdead = false;                                         // gave up once: do not wait again
+                auto xload = [&](int t) -> unsigned {
+                    const int tc = t < xt_hi ? t : xt_hi;
+                    return __hip_atomic_load(xr + TC * tc + (lane & (TC - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                auto xprime = [&]() {
+                    if constexpr (PAIR) {
+                        if (xsub) {
+#pragma unroll
+                            for (int i = 0; i < XAHEAD; ++i) xq[i] = xload(t_lo + i);
+                        }
+                    }
+                };
+                auto xput = [&](int u, int t) {                             // tile t is being staged (u: its queue slot)
+                    if constexpr (PAIR) {
+                        if (xsub) {
+                            unsigned cur = xq[u];
+                            xq[u] = xload(t + XAHEAD);
+                            if (t <= xt_hi) {
+                                // (the first test stands outside the loop, and the loop starts with its load: a loop
+                                // header that also tested the queued value made hipcc wait for EVERY load in flight
+                                // there -- s_waitcnt vmcnt(0) on the path that never polls)
+                                if (__builtin_expect(__ballot(cur == XRING_EMPTY) != 0ull, 0) && !xdead) {
+                                    int spins = 0;
+                                    do {
+                                        if (++spins > XRING_SPIN_LIMIT) {    // (cannot happen: the other half never waits)
+                                            if (lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+                                            xdead = true;
+                                            break;
+                                        }
+                                        __builtin_amdgcn_s_sleep(8);
+                                        cur = xload(t);
+                                    } while (__ballot(cur == XRING_EMPTY) != 0ull);
+                                }
+                                ring[(t & (RING_T - 1)) * RING_LD + lane] = __builtin_bit_cast(float, cur);   // (w == 0)
+                            }
+                        }
+                    }
+                };
                 if (VT == VT_F32) {
                     const int rr = lane >> 3, cg = lane & 7;
                     float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 4 * cg;
@@ -861,7 +964,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     for (int k = 0; k < 8; ++k) {
                         // rows past the utterance's own text (padding: often -inf log-probs) are replaced
                         // by its last row: they are never read by the DP and must not trip the finiteness scan
-                        int r = RPW * w + 8 * k + rr - 1;
+                        int r = RPW * gw + 8 * k + rr - 1;
                         r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
                         rowoff[k] = (unsigned)r * (unsigned)p.Ty;
                     }
@@ -895,12 +998,16 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     };
     #pragma unroll
                     for (int d = 0; d < DEPTH; ++d) issue(buf[d], t_lo + d);
+                    xprime();
                     for (int i = 0; i < t_lo + w; ++i) PHASE_BARRIER();
-                    for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+                    for (int i0 = 0; i0 < ntiles; i0 += UNR) {
     #pragma unroll
-                        for (int d = 0; d < DEPTH; ++d) {
-                            const int t = t_lo + i0 + d;
+                        for (int u = 0; u < UNR; ++u) {
+                            const int d = u % DEPTH;
+                            const int t = t_lo + i0 + u;
                             if (t <= t_hi) {
+                                xput(u, t);
+                                xforward(t - 2);
                                 float *dst = mytiles + (t & 1) * 64 * TILE_LD;
                                 if (t == ntb - 1) {
                                     // frames >= t_y (mel padding, or past the row's end) never matter: zero them
@@ -944,7 +1051,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     for (int k = 0; k < 4; ++k) {
                         // LDS row slot 16k+rr <-> text row 63w + 16k + rr - 1; rows outside the utterance's own text
                         // are replaced by its last row (never read by the DP, must not trip the finiteness scan)
-                        int r = RPW * w + 16 * k + rr - 1;
+                        int r = RPW * gw + 16 * k + rr - 1;
                         r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
                         voff[k] = ((unsigned)r * (unsigned)p.Ty + 8u * (unsigned)cg) * 2u;
                     }
@@ -960,12 +1067,16 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     };
 #pragma unroll
                     for (int d = 0; d < DEPTH; ++d) issue(d, t_lo + d);
+                    xprime();
                     for (int i = 0; i < t_lo + w; ++i) PHASE_BARRIER();
-                    for (int i0 = 0; i0 < ntiles; i0 += DEPTH) {
+                    for (int i0 = 0; i0 < ntiles; i0 += UNR) {
 #pragma unroll
-                        for (int d = 0; d < DEPTH; ++d) {
-                            const int t = t_lo + i0 + d;
+                        for (int u = 0; u < UNR; ++u) {
+                            const int d = u % DEPTH;
+                            const int t = t_lo + i0 + u;
                             if (t <= t_hi) {
+                                xput(u, t);
+                                xforward(t - 2);
                                 float *dst = mytiles + (t & 1) * 64 * TILE_LD;
                                 const int c0 = TC * t + 8 * cg;
                                 const bool tail = (t == ntb - 1);   // frames >= t_y never matter: zero them
@@ -1002,13 +1113,32 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                     }
                 }
                 if (absbits(nf) >= 0x7F800000u) flagp[0] = 1;   // benign race: every writer stores 1
-                for (int i = 0; i < ntb + NW - w - t_hi - 1; ++i) PHASE_BARRIER();
+                const int xb = xforward_tail();
+                for (int i = xb; i < ntb + NW - w - t_hi - 1; ++i) PHASE_BARRIER();
             } else {
                 for (int i = 0; i < ntb + NW; ++i) PHASE_BARRIER();
             }
         }
         ALIGNER_STAMP(4);
         __syncthreads();
+    }
+    if (PAIR && paired) {
+        if (half == 0) {
+            // this half's decision words are written (the barrier waited for every wave's stores): hand them over, with
+            // what its loaders saw, and leave -- the other workgroup finishes the utterance
+            if (tid == 0) __hip_atomic_store(p.xflag + b, flagp[0] != 0 ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            int v, spins = 0;
+            while ((v = __hip_atomic_load(p.xflag + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == (int)XRING_EMPTY) {
+                if (++spins > XRING_SPIN_LIMIT) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (v == 2) flagp[0] = 1;
+        }
+        __syncthreads();
+        __threadfence();
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
     // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
@@ -1100,7 +1230,7 @@ __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask
 // --------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t status_off, len_off, starts_off, bits_off, dump_off, total;
+    size_t status_off, len_off, starts_off, bits_off, dump_off, xring_off, xring_bytes, total;
     int NT, ROWS;
 };
 
@@ -1117,7 +1247,10 @@ static WsLayout ws_layout(int B, int Tx, int Ty) {
     L.starts_off = align_up(L.len_off + (size_t)2 * B * sizeof(int), 256);
     L.bits_off = align_up(L.starts_off + (size_t)B * (Tx + 1) * sizeof(int), 256);
     L.dump_off = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
-    L.total = align_up(L.dump_off + (size_t)B * 4 * 64 * sizeof(float), 256);
+    // two workgroups per utterance: the boundary row between them, 32 words per tile, and a done word (PAIR)
+    L.xring_off = align_up(L.dump_off + (size_t)B * 4 * 64 * sizeof(float), 256);
+    L.xring_bytes = align_up((size_t)B * L.NT * TC * sizeof(unsigned) + (size_t)B * sizeof(int), 256);
+    L.total = L.xring_off + L.xring_bytes;
     return L;
 }
 
@@ -1166,6 +1299,21 @@ static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, siz
     }
     if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 0, VT_F32>, grid, block, lds, s, p);
     return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 1, VT_F32>, grid, block, lds, s, p);
+}
+
+// two workgroups per utterance (grid 2B), 16-byte loaders only
+static int launch_pair(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
+    dim3 grid(2 * p.B), block(4 * 128);
+    if (vt == VT_BF16) {
+        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_BF16, true>, grid, block, lds, s, p);
+        return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_BF16, true>, grid, block, lds, s, p);
+    }
+    if (vt == VT_F16) {
+        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_F16, true>, grid, block, lds, s, p);
+        return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_F16, true>, grid, block, lds, s, p);
+    }
+    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_F32, true>, grid, block, lds, s, p);
+    return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_F32, true>, grid, block, lds, s, p);
 }
 
 template <int R, int VT>
@@ -1227,6 +1375,8 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.stamps = g_debug_stamps;
     p.dump = nullptr;
     p.qout = nullptr;
+    p.xring = reinterpret_cast<unsigned *>(wsb + L.xring_off);
+    p.xflag = reinterpret_cast<int *>(wsb + L.xring_off + (size_t)B * L.NT * TC * sizeof(unsigned));
     if (flags & ALIGNER_F_WRITE_Q) {
         if (vt != VT_F32 || (flags & ALIGNER_F_STRICT_MASK))
             return fail(ALIGNER_EINVAL, "ALIGNER_F_WRITE_Q takes fp32 scores without a strict mask (maximum_path_c's contract)");
@@ -1243,6 +1393,22 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                      (size_t)Tx * (size_t)Ty * 4 < (1ull << 31);
 
     const int nw_need = (Tx + RPW - 1) / RPW;
+    // Long text (5..8 waves of rows) on a batch that leaves CUs idle: two workgroups per utterance, each the
+    // four-wave form with one compute wave per SIMD (maxpath_pipelined_kernel<.., PAIR>).  A full machine gains
+    // nothing from the split, so it is taken only while every workgroup gets a CU of its own; and the second half
+    // runs some twenty phases behind the first (the boundary row's trip through memory), which a sweep shorter
+    // than about 60 tiles does not win back ([64,400,2000]: 77 us against 72) -- taken from 96 tiles on.
+    if (!(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_ONE_CU)) && nw_need > 4 && nw_need <= 8 && vec &&
+        ((flags & ALIGNER_F_TWO_CUS) || (2 * B <= device_cu_count() && L.NT >= 96))) {
+        const size_t fwd = align_up(((size_t)4 * (2 * 64 * TILE_LD + RING_T * RING_LD) + RING_T * RING_LD) * 4 + 16, 16);
+        p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
+        if (p.WT > 0 && fwd <= lds_max && starts_bytes(Tx) <= fwd) {
+            size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
+            if (lds < fwd) lds = fwd;
+            ALIGNER_HIP_CHECK(hipMemsetAsync(wsb + L.xring_off, 0xFF, L.xring_bytes, s));
+            return launch_pair(p, maskmode, vt, lds, s);
+        }
+    }
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8 && (vt == VT_F32 || vec)) {
         const int NW = (nw_need <= 4 && vt != VT_F32) ? 4 : nw_need <= 1 ? 1 : nw_need <= 2 ? 2 : nw_need <= 4 ? 4 : 8;
         const size_t fwd = align_up((size_t)NW * (2 * 64 * TILE_LD + RING_T * RING_LD) * 4 + 16, 16);
@@ -1450,6 +1616,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     p.stamps = g_debug_stamps;
     p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
     p.qout = nullptr;
+    p.xring = nullptr; p.xflag = nullptr;
     const size_t lds_max = (size_t)lds_limit();
     const FusedLds FL = fused_lds_layout();
     p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);

@@ -62,6 +62,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           want_tok: bool = False, want_durations: bool = True,
           max_neg_val: float = -1e9, compat_tx_gt_ty: bool = False,
           force_generic: bool = False, no_prev_table: bool = False, stream_path: bool = False,
+          cus_per_utterance: Optional[int] = None,
           out_path: Optional[torch.Tensor] = None) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
@@ -72,7 +73,11 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
     mask element-wise (__init__.py:11).  Asynchronous on the current stream.
     stream_path: write the dense path with non-temporal stores (ALIGNER_F_STREAM_PATH: worth it when other batches
     are in flight on the GPU and nothing reads the path back at once).
+    cus_per_utterance: None = the library decides (long text on a long mel axis in a small batch runs as two
+    workgroups per utterance, ALIGNER_F_ONE_CU / ALIGNER_F_TWO_CUS otherwise); the results do not depend on it.
     """
+    if cus_per_utterance not in (None, 1, 2):
+        raise ValueError("cus_per_utterance must be None, 1 or 2")
     if value.dim() != 3:
         raise ValueError(f"value must be [b, t_x, t_y], got {tuple(value.shape)}")
     if not value.is_cuda:
@@ -138,7 +143,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     (_lib.F_COMPAT_TXGTTY if compat_tx_gt_ty else 0) | \
                     (_lib.F_FORCE_GENERIC if force_generic else 0) | \
                     (_lib.F_NO_PREV_TABLE if no_prev_table else 0) | \
-                    (_lib.F_STREAM_PATH if stream_path else 0)
+                    (_lib.F_STREAM_PATH if stream_path else 0) | \
+                    (_lib.F_ONE_CU if cus_per_utterance == 1 else _lib.F_TWO_CUS if cus_per_utterance == 2 else 0)
             _lib.check(lib.aligner_maxpath(
                 v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
                 ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))

@@ -69,6 +69,15 @@ extern "C" {
                                       tensors of other batches in flight from the caches (three batches in
                                       flight: 39.9 -> 33.8 us per step at [64,200,1000]; one batch alone is
                                       2 us slower).  The caller's choice; off by default                */
+#define ALIGNER_F_ONE_CU       256 /* never split an utterance over two workgroups.  By default text of 253..504
+                                      rows over 3072 or more mel frames, in a batch that leaves half the CUs
+                                      idle (2 B <= CU count), runs as two workgroups per utterance, each on its
+                                      own CU: same results, the sweep bound by two CUs' vector units instead of
+                                      one's (long-form [8,500,4000]: 134 -> 106 us).  The boundary row between the
+                                      halves travels through the workspace, which is why the call then starts
+                                      with a small hipMemsetAsync on the same stream */
+#define ALIGNER_F_TWO_CUS      512 /* take the two-workgroup form whenever the text has 253..504 rows, whatever
+                                      the batch size and mel length (testing; a short sweep loses by it) */
 #define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside
                                       the band, in place, exactly as the reference does (core.pyx:18,30:
                                       `value[x, y] = max(v_cur, v_prev) + value[x, y]`).  Takes the

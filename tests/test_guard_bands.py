@@ -48,11 +48,11 @@ class Fenced:
 
 
 SHAPES = [(1, 1, 1), (3, 7, 13), (2, 63, 64), (4, 64, 257), (2, 127, 1000), (3, 200, 1001), (2, 253, 300),
-          (1, 300, 700), (2, 505, 2100), (1, 600, 650)]
+          (1, 300, 700), (2, 505, 2100), (1, 600, 650), (3, 504, 1000), (2, 330, 3104)]
 
 
 @pytest.mark.parametrize("B,Tx,Ty", SHAPES)
-@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE, _lib.F_STREAM_PATH])
+@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE, _lib.F_STREAM_PATH, _lib.F_TWO_CUS])
 def test_alignment_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, flags):
     lib = _lib.load()
     rng = np.random.default_rng(B * 1000 + Tx + Ty)

@@ -460,3 +460,73 @@ def test_token_index_on_a_very_long_mel_axis(dev):
 
 
 
+
+
+def test_two_workgroups_per_utterance(dev):
+    """Text of 253..504 rows can run as two workgroups per utterance (two CUs; the boundary row between the halves
+    travels through the workspace, the second half runs the backtrack).  The split must not change a bit: against the
+    oracle, forced on at small sizes -- ragged batches where some utterances have no rows for the second half, long
+    tokens, ties, a non-finite score in either half (exact fallback run by the second workgroup), 16-bit scores,
+    strict masks -- and forced off."""
+    rng = np.random.default_rng(2025)
+    cases = [(3, 300, 700), (5, 504, 640), (2, 253, 2100), (4, 400, 1000), (9, 330, 512)]
+    for it, (B, Tx, Ty) in enumerate(cases):
+        v = (rng.standard_normal((B, Tx, Ty)) if it % 2 == 0 else rng.integers(-2, 3, (B, Tx, Ty))).astype(np.float32)
+        for b in range(B):
+            v[b, int(rng.integers(0, Tx)), :] += 2.5                         # a token that runs for hundreds of frames
+        ty = rng.integers(Ty // 2, Ty + 1, B).astype(np.int32)
+        ty[0] = Ty
+        tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
+        tx[0] = Tx
+        if B > 1: tx[1] = min(200, ty[1])                                    # nothing for the second workgroup
+        if B > 2: tx[2] = min(253, ty[2])                                    # one row for it
+        want = _oracle_path(v, tx, ty)
+        for cus in (2, 1):
+            p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus)
+            assert np.array_equal(p, want), (it, cus)
+            _check_consistency(p, tok, dur, tx, ty)
+    import aligner_amd
+    assert aligner_amd.read_status(dev) == 0
+    # non-finite scores: in the first half's rows, in the second's, in both
+    B, Tx, Ty = 4, 420, 600
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    v[0, 17, 300] = np.inf
+    v[1, 400, 450] = -np.inf
+    v[2, 100, 200] = np.nan; v[2, 300, 500] = np.inf
+    tx = np.array([420, 420, 420, 400], np.int32); ty = np.array([600, 590, 600, 600], np.int32)
+    want = _oracle_path(v, tx, ty)
+    for cus in (2, 1):
+        p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus)
+        assert np.array_equal(p, want), cus
+    # 16-bit scores and a strict mask
+    for dt in (torch.bfloat16, torch.float16):
+        B, Tx, Ty = 3, 380, 960
+        v16 = torch.from_numpy(rng.standard_normal((B, Tx, Ty)).astype(np.float32)).to(dt)
+        tx = np.array([380, 300, 254], np.int32); ty = np.array([960, 900, 512], np.int32)
+        want = _oracle_path(v16.float().numpy(), tx, ty)
+        for cus in (2, 1):
+            res = aligner_amd.align(v16.to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
+                                    path_dtype=torch.int32, cus_per_utterance=cus)
+            assert np.array_equal(res.path.cpu().numpy(), want), (dt, cus)
+    B, Tx, Ty = 2, 300, 640
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([300, 280], np.int32); ty = np.array([640, 600], np.int32)
+    mask = np.zeros((B, Tx, Ty), np.float32)
+    for b in range(B): mask[b, :tx[b], :ty[b]] = 1.0
+    want = _oracle_path(v * mask, tx, ty)
+    for cus in (2, 1):
+        res = aligner_amd.align(torch.from_numpy(v).to(dev), mask=torch.from_numpy(mask).to(dev), strict_mask=True,
+                                path_dtype=torch.int32, cus_per_utterance=cus)
+        assert np.array_equal(res.path.cpu().numpy(), want), cus
+
+
+def test_two_workgroups_full_size_long_form(appendix_a, dev):
+    """BASELINE config 5's shape through the form the library picks for it (two workgroups per utterance) and through
+    the one-workgroup form: the same path, equal to the reference's hash."""
+    import aligner_amd
+    rec, _ = appendix_a
+    v, tx, ty = _config("C5-longform")
+    for cus in (None, 2, 1):
+        p, _, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus)
+        assert synth.sha256_of(p) == rec["C5-longform"]["path_sha256"], cus
+    assert aligner_amd.read_status(dev) == 0
