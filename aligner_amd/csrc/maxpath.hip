@@ -1301,6 +1301,11 @@ static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, siz
     return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 1, VT_F32>, grid, block, lds, s, p);
 }
 
+__global__ __launch_bounds__(256) void xring_fill_kernel(uint4 *dst, int n16) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = make_uint4(XRING_EMPTY, XRING_EMPTY, XRING_EMPTY, XRING_EMPTY);
+}
+
 // two workgroups per utterance (grid 2B), 16-byte loaders only
 static int launch_pair(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
     dim3 grid(2 * p.B), block(4 * 128);
@@ -1405,7 +1410,12 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
         if (p.WT > 0 && fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
             if (lds < fwd) lds = fwd;
-            ALIGNER_HIP_CHECK(hipMemsetAsync(wsb + L.xring_off, 0xFF, L.xring_bytes, s));
+            // the boundary ring and the done words start every launch as 0xFFFFFFFF (a kernel of our own: it is a
+            // plain node in a captured graph, and a third of hipMemsetAsync's fill kernel in time)
+            const int n16 = (int)(L.xring_bytes / 16);
+            hipLaunchKernelGGL(xring_fill_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<uint4 *>(wsb + L.xring_off), n16);
+            ALIGNER_HIP_CHECK(hipGetLastError());
             return launch_pair(p, maskmode, vt, lds, s);
         }
     }

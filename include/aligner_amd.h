@@ -75,7 +75,7 @@ extern "C" {
                                       own CU: same results, the sweep bound by two CUs' vector units instead of
                                       one's (long-form [8,500,4000]: 134 -> 106 us).  The boundary row between the
                                       halves travels through the workspace, which is why the call then starts
-                                      with a small hipMemsetAsync on the same stream */
+                                      with a small fill kernel on the same stream */
 #define ALIGNER_F_TWO_CUS      512 /* take the two-workgroup form whenever the text has 253..504 rows, whatever
                                       the batch size and mel length (testing; a short sweep loses by it) */
 #define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside

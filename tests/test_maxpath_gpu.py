@@ -530,3 +530,44 @@ def test_two_workgroups_full_size_long_form(appendix_a, dev):
         p, _, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus)
         assert synth.sha256_of(p) == rec["C5-longform"]["path_sha256"], cus
     assert aligner_amd.read_status(dev) == 0
+
+
+def test_two_workgroups_in_a_replayed_graph(dev):
+    """The two-workgroup form starts its launch by refilling the boundary ring (hipMemsetAsync on the caller's stream):
+    captured into a HIP graph with the kernels, so a replay on NEW scores in the same buffers must not meet the
+    previous replay's boundary rows.  C ABI straight, as a serving loop would drive it."""
+    from aligner_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(99)
+    B, Tx, Ty = 3, 330, 704
+    tx = np.array([330, 300, 200], np.int32); ty = np.array([704, 650, 704], np.int32)
+    d_v = torch.zeros((B, Tx, Ty), dtype=torch.float32, device=dev)
+    d_tx, d_ty = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    path = torch.zeros((B, Tx, Ty), dtype=torch.int32, device=dev)
+    dur = torch.zeros((B, Tx), dtype=torch.int32, device=dev)
+    ws = torch.zeros(lib.aligner_maxpath_workspace_bytes(B, Tx, Ty), dtype=torch.uint8, device=dev)
+
+    def launch():
+        _lib.check(lib.aligner_maxpath(d_v.data_ptr(), _lib.DT_F32, None, 0, d_tx.data_ptr(), d_ty.data_ptr(),
+                                       path.data_ptr(), _lib.DT_I32, None, dur.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       B, Tx, Ty, -1e9, _lib.F_TWO_CUS, torch.cuda.current_stream().cuda_stream))
+
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        launch()                                           # (first launch outside the capture: LDS attribute grants)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        launch()
+    for trial in range(4):
+        v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+        d_v.copy_(torch.from_numpy(v))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        want = _oracle_path(v, tx, ty)
+        assert np.array_equal(path.cpu().numpy(), want), trial
+        assert np.array_equal(dur.cpu().numpy(), want.sum(2)), trial
+    st = np.zeros(1, np.int32)
+    _lib.check(lib.aligner_maxpath_read_status(ws.data_ptr(), st.ctypes.data, None))
+    assert int(st[0]) == 0
