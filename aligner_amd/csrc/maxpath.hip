@@ -1410,8 +1410,8 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
         if (p.WT > 0 && fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
             if (lds < fwd) lds = fwd;
-            // the boundary ring and the done words start every launch as 0xFFFFFFFF (a kernel of our own: it is a
-            // plain node in a captured graph, and a third of hipMemsetAsync's fill kernel in time)
+            // the boundary ring and the done words start every launch as 0xFFFFFFFF (a kernel of our own: a captured
+            // hipMemsetAsync node did not refill the ring when the graph was replayed)
             const int n16 = (int)(L.xring_bytes / 16);
             hipLaunchKernelGGL(xring_fill_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s,
                                reinterpret_cast<uint4 *>(wsb + L.xring_off), n16);
