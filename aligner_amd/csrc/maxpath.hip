@@ -737,9 +737,9 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 // block B + b waves NW..2NW-1).  A CU's VALU is what a long text (more than 4 x 63 rows: two compute waves per
 // SIMD) is bound by, and a small batch leaves most CUs idle.  The boundary row between the halves goes through
 // global memory: the first half's last compute wave publishes into LDS as if a fifth wave followed, its loader wave
-// forwards those 32 values per tile with agent-scope stores into a ring the host filled with 0xFFFFFFFF (the compute
+// forwards those 32 values per tile with agent-scope stores into a ring that xring_fill_kernel set to 0xFFFFFFFF (the compute
 // waves' code is the one-workgroup code: any store of theirs that hipcc could not tell from a load made every tile
-// wait for the previous tile's stores), the second half's first loader wave reads them two tiles ahead and polls until no
+// wait for the previous tile's stores), the second half's first loader wave reads them four tiles ahead and polls until no
 // word is the filler (a running score is finite; a NaN with that bit pattern is rewritten before it is stored) --
 // the data is its own flag, nothing waits for a store to complete.  The first half never waits for the second
 // (lower block indices are dispatched first), so the pair cannot deadlock; the second half waits once more, for
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             if (active) {
                 float nf = 0.f;                             // maximum |score| seen, NaN-propagating (scan4)
                 // PAIR, first loader wave of the second workgroup: the row above this workgroup's first row comes
-                // from the other CU (see the kernel's header).  Read two tiles ahead like the scores, polled when its
+                // from the other CU (see the kernel's header).  Read four tiles ahead (XAHEAD), polled when its
                 // tile is staged, handed to compute wave 0 through the ring slot its ghost lane reads anyway.
                 const bool xsub = PAIR && paired && half == 1 && w == 0;
                 int xt_hi = (ty - tx + RPW * (gw - 1) + RPW - 1) / TC;      // last tile wave gw - 1 publishes
