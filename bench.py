@@ -527,7 +527,7 @@ def main():
         # command (tools/pmc_traffic.py; gfx950 FETCH_SIZE correction applied) and committed under profiles/ --
         # not measured by this run, so the line names the file (and with it the build) the figure comes from
         traffic, traffic_src = None, None
-        for name in ("r02f_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        for name in ("r02h_pmc_hbm_traffic.json", "r02f_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
