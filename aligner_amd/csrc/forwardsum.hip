@@ -401,27 +401,33 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
     const bool ghost = lane == 0, rowok = row < tx;
     float drift = 0.f;
     double C = 0.0, drift_d = 0.0;
+    // stagers: the tile of the NEXT phase is already in flight while this phase's tile goes into LDS (loaded and
+    // waited for inside one phase, a tile cost a memory round trip per phase: staging alone took as long as the sweep)
+    float vnext[SY_TW];
+    auto stage_issue = [&](int tl) {                          // unconditional loads (row and frame clamped into the utterance)
+        const int tc = tl < ntl ? tl : ntl - 1;
+        const int y0 = tc * SY_TW;
+#pragma unroll
+        for (int i = 0; i < SY_TW; ++i) {
+            const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
+            int rg = 63 * w + r - 1;
+            rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
+            const int yc = y0 + c < ty ? y0 + c : ty - 1;
+            vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+        }
+    };
+    if (!sweeper) stage_issue(0);
     for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
         if (!sweeper) {
             const int tl = ph - w, ts = ph - 2 - w;
             if (tl >= 0 && tl < ntl) {
-                // unconditional loads (row and frame clamped into the utterance), whole tile in flight
                 float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
-                const int y0 = tl * SY_TW;
-                float v[SY_TW];
-#pragma unroll
-                for (int i = 0; i < SY_TW; ++i) {
-                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
-                    int rg = 63 * w + r - 1;
-                    rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
-                    const int yc = y0 + c < ty ? y0 + c : ty - 1;
-                    v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-                }
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dst[c * SY_LD + r] = fs_in(v[i]);
+                    dst[c * SY_LD + r] = fs_in(vnext[i]);
                 }
+                stage_issue(tl + 1);
             }
             if (ts >= 0 && ts < ntl) {
                 const float *src = tout + (w * 2 + (ts & 1)) * SY_TILE;
