@@ -401,24 +401,25 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
     const bool ghost = lane == 0, rowok = row < tx;
     float drift = 0.f;
     double C = 0.0, drift_d = 0.0;
-    // stagers: the tile of the NEXT phase is already in flight while this phase's tile goes into LDS (loaded and
-    // waited for inside one phase, a tile cost a memory round trip per phase: staging alone took as long as the sweep)
-    float vnext[SY_TW];
-    auto stage_issue = [&](int tl) {                          // unconditional loads (row and frame clamped into the utterance)
-        const int tc = tl < ntl ? tl : ntl - 1;
-        const int y0 = tc * SY_TW;
-#pragma unroll
-        for (int i = 0; i < SY_TW; ++i) {
-            const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
-            int rg = 63 * w + r - 1;
-            rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
-            const int yc = y0 + c < ty ? y0 + c : ty - 1;
-            vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-        }
-    };
-    if (!sweeper) stage_issue(0);
-    for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
-        if (!sweeper) {
+    // Two loops, one per role (same phase count): the stagers' tile in flight is then live in their loop only
+    if (!sweeper) {
+        // stagers: the tile of the NEXT phase is already in flight while this phase's tile goes into LDS (loaded and
+        // waited for inside one phase, a tile cost a memory round trip per phase: staging alone took as long as the sweep)
+        float vnext[SY_TW];
+        auto stage_issue = [&](int tl) {                          // unconditional loads (row and frame clamped into the utterance)
+            const int tc = tl < ntl ? tl : ntl - 1;
+            const int y0 = tc * SY_TW;
+    #pragma unroll
+            for (int i = 0; i < SY_TW; ++i) {
+                const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
+                int rg = 63 * w + r - 1;
+                rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
+                const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+            }
+        };
+        stage_issue(0);
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
             const int tl = ph - w, ts = ph - 2 - w;
             if (tl >= 0 && tl < ntl) {
                 float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
@@ -440,7 +441,10 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
                 }
                 if (lane < SY_TW && y0 + lane < ty) offs[y0 + lane] = toff[(w * 2 + (ts & 1)) * SY_TW + lane];
             }
-        } else {
+            fs_lds_barrier();
+        }
+    } else {
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
             const int t = ph - 1 - w;
             if (t >= 0 && t < ntl) {
                 const int y0 = t * SY_TW, buf = t & 1;
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
                 else                 frames(std::true_type{});
                 if (lane < SY_TW) myoff[lane] = Ck;
             }
+            fs_lds_barrier();
         }
-        fs_lds_barrier();
     }
 }
 
@@ -529,29 +533,41 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
     const bool ghost = lane == 63, rowok = row < tx;
     float drift = 0.f;
     double D = 0.0, Dl = -logz, drift_d = 0.0;                // Dl = D - log Z
-    for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
-        if (!sweeper) {
+    // Two loops, one per role (the phase count is the same): written as one loop with the role tested inside, the
+    // stagers' tile in flight was live through the sweepers' code as well and the kernel spilled (236 -> 493 us).
+    if (!sweeper) {
+        // the NEXT phase's tile (log-probs, alpha, offsets) is in flight while this phase's goes into LDS
+        float vnext[SY_TW], unext[SY_TW];
+        double onext = 0.0;
+        auto stage_issue = [&](int kl) {                      // tile counted from the end, clamped
+            const int kc = kl < ntl ? kl : ntl - 1;
+            const int y0 = (ntl - 1 - kc) * SY_TW;
+#pragma unroll
+            for (int i = 0; i < SY_TW; ++i) {
+                const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                int rg = 63 * w + r;
+                rg = rg < tx ? rg : tx - 1;
+                const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+            }
+            const int yo = y0 + (lane & (SY_TW - 1));
+            onext = offs[yo < ty ? yo : ty - 1];
+        };
+        stage_issue(0);
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
             const int kl = ph - wr, ks = ph - 2 - wr;         // tile counted from the end
             if (kl >= 0 && kl < ntl) {
                 const int t = ntl - 1 - kl, y0 = t * SY_TW;
                 float *dlp = tlp + (w * 2 + (kl & 1)) * SY_TILE, *dal = tal + (w * 2 + (kl & 1)) * SY_TILE;
-                float v[SY_TW], u[SY_TW];
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    int rg = 63 * w + r;
-                    rg = rg < tx ? rg : tx - 1;
-                    const int yc = y0 + c < ty ? y0 + c : ty - 1;
-                    v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-                    u[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+                    dlp[c * SY_LD + r] = fs_in(vnext[i]);
+                    dal[c * SY_LD + r] = unext[i];
                 }
-#pragma unroll
-                for (int i = 0; i < SY_TW; ++i) {
-                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dlp[c * SY_LD + r] = fs_in(v[i]);
-                    dal[c * SY_LD + r] = u[i];
-                }
-                if (lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? offs[y0 + lane] : 0.0;
+                if (lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
+                stage_issue(kl + 1);
             }
             if (ks >= 0 && ks < ntl) {
                 const float *src = tgr + (w * 2 + (ks & 1)) * SY_TILE;
@@ -563,7 +579,10 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                     if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
                 }
             }
-        } else {
+            fs_lds_barrier();
+        }
+    } else {
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
             const int k = ph - 1 - wr;
             if (k >= 0 && k < ntl) {
                 const int buf = k & 1, y0 = (ntl - 1 - k) * SY_TW;
@@ -624,8 +643,8 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                 else        frames(std::true_type{});
                 if (lane < SY_TW) mydof[lane] = Dk;
             }
+            fs_lds_barrier();
         }
-        fs_lds_barrier();
     }
 }
 
