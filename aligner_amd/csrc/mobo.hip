@@ -75,7 +75,10 @@ __device__ __forceinline__ void mb_block_max(const float *__restrict__ x, float 
         const int o = blk * (D + 1);
         float M = MB_NEG;
 #pragma unroll 8
-        for (int r = 0; r < D; ++r) M = fmaxf(M, x[o + r]);       // (unrolled: the LDS reads of a batch go out together)
+        for (int r = 0; r < D; ++r) {                               // (unrolled: the LDS reads of a batch go out together)
+            const float v = x[o + r];
+            M = (v > M) ? v : M;          // fmaxf(M, v) for a never-NaN M -- as fmaxf hipcc vectorised this reduction
+        }                                 // with a NaN test and an exec-mask exit per element
         bmax[blk] = (M > 0.5f * MB_NEG) ? ceilf(M) : MB_NEG;      // an INTEGER reference: two blocks' sums are brought
                                                                   // to a common scale by an exact ldexp (mb_window)
     }
