@@ -124,9 +124,12 @@ __device__ __forceinline__ float mb_window(float M1, double S1, float M2, double
 
 // One block per thread: position of the maximum of every prefix (ties: the LARGEST position) and of every
 // suffix (ties: the largest position as well), as offsets inside the block.
+// (`first`: the thread that takes block 0 -- the caller runs this scan on other waves than the block maxima that
+// share its phase, so the two serial scans of phase D go side by side)
 __device__ __forceinline__ void mb_scan_argmax(const float *__restrict__ x, unsigned short *__restrict__ ipre,
-                                               unsigned short *__restrict__ isuf, int nblk, int D) {
-    for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
+                                               unsigned short *__restrict__ isuf, int nblk, int D, int first) {
+    const int nthr = (int)blockDim.x, t0 = ((int)threadIdx.x - first + nthr) % nthr;
+    for (int blk = t0; blk < nblk; blk += nthr) {
         const int o = blk * (D + 1);
         float m = x[o];
         int im = 0;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(MB_THREADS) void mobo_forward_kernel(MoboParams p) 
         mb_lds_barrier();
         // ---- D: block scans of U (sums) and V (argmax) ----
         mb_block_max(sA, sM, nblk, D);
-        mb_scan_argmax(sV, iP, iS, nblk, D);
+        mb_scan_argmax(sV, iP, iS, nblk, D, (nthr >= 2 * nblk) ? (nthr / 2) & ~63 : 0);
         mb_lds_barrier();
         MB_FOR_POS({ sT[x] = mb_pow2(sA[x] - sM[blk]); });
         mb_lds_barrier();
