@@ -498,6 +498,14 @@ def test_two_workgroups_per_utterance(dev):
     for cus in (2, 1):
         p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus)
         assert np.array_equal(p, want), cus
+    # a non-finite max_neg_val: no fast sweep at all, the second workgroup runs the exact one for the whole utterance
+    B, Tx, Ty = 2, 300, 400
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([300, 260], np.int32); ty = np.array([400, 380], np.int32)
+    want = _oracle_path(v, tx, ty, neg=-np.inf)
+    for cus in (2, 1):
+        p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=cus, max_neg_val=float("-inf"))
+        assert np.array_equal(p, want), cus
     # 16-bit scores and a strict mask
     for dt in (torch.bfloat16, torch.float16):
         B, Tx, Ty = 3, 380, 960
