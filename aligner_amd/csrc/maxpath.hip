@@ -1400,11 +1400,13 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     const int nw_need = (Tx + RPW - 1) / RPW;
     // Long text (5..8 waves of rows) on a batch that leaves CUs idle: two workgroups per utterance, each the
     // four-wave form with one compute wave per SIMD (maxpath_pipelined_kernel<.., PAIR>).  A full machine gains
-    // nothing from the split, so it is taken only while every workgroup gets a CU of its own; and the second half
-    // runs some twenty phases behind the first (the boundary row's trip through memory), which a sweep shorter
-    // than about 60 tiles does not win back ([64,400,2000]: 77 us against 72) -- taken from 96 tiles on.
+    // nothing from the split, and the second half runs some twenty phases behind the first (read-ahead, skew,
+    // forwarding, the boundary row's trip through memory).  Measured on full-length batches (in-kernel, two
+    // workgroups / one): [8,500,4000] 106 / 134 us, [8,500,2048] 68 / 76, [8,500,1536] 59 / 63, [8,500,1024] 50 / 50,
+    // [8,300,1536] 49 / 48; [16,400,2000] 65 / 75, [32,400,2000] 68 / 75, [64,400,2000] 74 / 76, [64,500,2048] 79 / 79:
+    // taken from 56 tiles on, for batches of at most an eighth of the CU count.
     if (!(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_ONE_CU)) && nw_need > 4 && nw_need <= 8 && vec &&
-        ((flags & ALIGNER_F_TWO_CUS) || (2 * B <= device_cu_count() && L.NT >= 96))) {
+        ((flags & ALIGNER_F_TWO_CUS) || (8 * B <= device_cu_count() && L.NT >= 56))) {
         const size_t fwd = align_up(((size_t)4 * (2 * 64 * TILE_LD + RING_T * RING_LD) + RING_T * RING_LD) * 4 + 16, 16);
         p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
         if (p.WT > 0 && fwd <= lds_max && starts_bytes(Tx) <= fwd) {

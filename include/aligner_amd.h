@@ -70,8 +70,8 @@ extern "C" {
                                       flight: 39.9 -> 33.8 us per step at [64,200,1000]; one batch alone is
                                       2 us slower).  The caller's choice; off by default                */
 #define ALIGNER_F_ONE_CU       256 /* never split an utterance over two workgroups.  By default text of 253..504
-                                      rows over 3072 or more mel frames, in a batch that leaves half the CUs
-                                      idle (2 B <= CU count), runs as two workgroups per utterance, each on its
+                                      rows over 1792 or more mel frames, in a batch of at most an eighth of the
+                                      CU count (B <= 32 on MI355X), runs as two workgroups per utterance, each on its
                                       own CU: same results, the sweep bound by two CUs' vector units instead of
                                       one's (long-form [8,500,4000]: 134 -> 106 us).  The boundary row between the
                                       halves travels through the workspace, which is why the call then starts
