@@ -1137,8 +1137,9 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
             }
             if (v == 2) flagp[0] = 1;
         }
+        // (thread 0's acquire has invalidated this CU's L1 and the XCD's L2 for everybody; the barrier orders the
+        // other waves' loads behind it -- a full fence by all eight waves here cost the kernel 2 us)
         __syncthreads();
-        __threadfence();
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
     // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
