@@ -69,6 +69,7 @@ SIGNATURES = {
     "aligner_forward_sum_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_beta_binomial_prior_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "aligner_boundary_search_workspace_bytes": (_sz, [_i, _i, _i]),
+    "aligner_boundary_search_workspace_bytes_ex": (_sz, [_i, _i, _i, _i]),
     "aligner_boundary_search": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_regulate_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -6,24 +6,32 @@
 //     P(b_i = j | b_{i-1} = k) = exp(e[i,j-1]) / sum_{m in A_i(k)} exp(e[i,m-1]),
 //     A_i(k) = (k, k+D] intersected with [lo_i, hi_i]   (the later tokens still fit: see the oracle).
 // Outputs: log_alpha[i,j-1] = log P(b_i = j) (sum-product), the MAP boundary sequence (max-product, ties: the
-// shortest token) with its log-probability, and -- a second, row-parallel kernel -- the soft alignment
+// shortest token) with its log-probability, and -- a row-parallel kernel -- the soft alignment
 // gamma[i,y] = P(b_{i-1} <= y < b_i).
 //
-// Shape of the computation.  Token rows are a dependent chain (row i needs row i-1); inside a row every boundary
-// position is independent, so lanes own positions and one workgroup owns one utterance (grid = batch, like the
-// alignment search).  Both steps of a row are sliding-window reductions of width D over the position axis,
+// Shape of the computation (round 3; round 2 ran everything on one CU per utterance, 5.7 ms at [8,500,4000]):
 //     L_i(k)      = logsumexp_{m in A_i(k)} e_i(m)                       (normaliser of the step out of k)
 //     la_i(j)     = e_i(j) + logsumexp_{k in [j-D, j)} (la_{i-1}(k) - L_i(k))
 //     delta_i(j)  = e_i(j) +    max    _{k in [j-D, j)} (delta_{i-1}(k) - L_i(k))   (+ argmax)
-// and a width-D window over blocks of D aligned positions is (a suffix of one block) + (a prefix of the next):
-// two lookups into per-block prefix / suffix sums instead of D terms.  The sums are fp64 (2^(v - block max), a
-// chain of plain adds) and the two parts of a window are only ever ADDED, so a window keeps full relative
-// precision however far below the row's bulk it lies (a row-wide prefix sum would cancel there, fp32 sums
-// normalised by one block maximum underflow).  The exp2s run one position per lane; only the adds of a block's
-// scan are serial (one block per thread, J/D threads busy).  All logs are base 2 inside (v_exp_f32 / v_log_f32 are exp2 / log2), "log 0" is the
-// finite -1e30, which absorbs every addend: no inf - inf.
+//  1. mobo_norm_kernel: L depends on the energies only, so it is computed for every (utterance, token, position)
+//     at once on the whole chip, before the chain starts.
+//  2. mobo_chain_kernel: token rows are a dependent chain, positions inside a row are independent, and a row
+//     only looks BACK (at most D positions).  So the positions of an utterance are cut into S segments, one
+//     workgroup (its own CU) each; segment s needs from segment s-1 only the last D entries of its row, which
+//     travel through a ring in the workspace whose words are their own flags (filled with 0xFFFFFFFF before the
+//     launch; never a value).  Data flows one way, so segment s simply runs a little behind segment s-1 and
+//     nobody waits for a consumer.  Rows in which a segment has no reachable position cost it a few stores.
+//  3. mobo_backtrack_kernel: the MAP sequence from the per-(token, position) durations, a batch of rows at a time
+//     (a step's position lies within t*D of the batch's start, so the batch's window is fetched at once).
+// Windows are summed directly, one position per lane, over an exact representation of every term:
+// u = M + log2(s) with an INTEGER M = ceil(u) and s = 2^(u-M) in (0.5, 1]; a window's sum is
+// sum_k ldexp(s_k, M_k - Mw) with Mw the largest M in the window -- every scaling is an exact power of two, the
+// reference is the window's own maximum, so a window keeps full relative precision however far below the row's
+// bulk it lies (the reason round 2 carried fp64 block sums).  All logs are base 2 inside (v_exp_f32 /
+// v_log_f32 are exp2 / log2), "log 0" is the finite -1e30.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 #include "aligner_amd.h"
@@ -32,24 +40,28 @@
 namespace aligner {
 
 constexpr float MB_NEG = -1e30f;                  // log 0
+constexpr float MB_DEADF = -1e7f;                 // anything below is "log 0" (|live values| stay far below 2^24)
+constexpr int MB_DEADM = -(1 << 24);              // integer part of a dead term
+constexpr unsigned MB_FILL = 0xFFFFFFFFu;         // ring filler (a NaN pattern no value ever has)
 constexpr float MB_LOG2E = 1.4426950408889634f, MB_LN2 = 0.6931471805599453f;
-constexpr int MB_THREADS = 1024;
+constexpr int MB_SPIN_LIMIT = 1 << 21;            // polls of one ring row before a segment gives up (~ seconds)
 
 struct MoboParams {
     const void *e;            // [B,Tx,Ty] fp32 / bf16 / fp16
-    int vt;                   // 0 f32, 1 bf16, 2 f16
     const int *t_xs, *t_ys;   // [B]
     float *log_alpha;         // nullable [B,Tx,Ty]
     int *boundaries;          // [B,Tx]
     int *durations;           // nullable [B,Tx]
     float *map_score;         // nullable [B]
+    float *Lw;                // workspace [B,Tx,Ty]: L_i(k), base 2, k = 0..Ty-1
     unsigned short *back;     // workspace [B,Tx,Ty+1]: duration of token i when it ends at j
-    int *status;              // workspace: ALIGNER_ST_BAD_LENGTHS when an utterance is infeasible
-    int B, Tx, Ty, D, P;      // P = padded positions (multiple of D, >= Ty+1)
+    unsigned *ring;           // workspace [B,S-1,Tx,3,D]: (M, s, v) of a segment's last D positions, row by row
+    int *failw;               // workspace [B]: 1 = a segment of this utterance gave up waiting
+    int *status;              // workspace: ALIGNER_ST_* bits
+    int B, Tx, Ty, D, S, nmax;
+    int drop_seg, spin_limit;  // testing (aligner_debug_set_option "mobo_drop_segment"): that segment publishes nothing
 };
 
-// raw bits of one energy (the load), and their value (the conversion): kept apart so that the loads of the next
-// row can be in flight, unconverted, while this row is computed
 template <int VT> __device__ __forceinline__ unsigned mb_load_raw(const void *base, size_t idx) {
     if (VT == 0) return static_cast<const unsigned *>(base)[idx];
     return static_cast<const unsigned short *>(base)[idx];
@@ -60,275 +72,444 @@ template <int VT> __device__ __forceinline__ float mb_value(unsigned raw) {
     return (float)__builtin_bit_cast(_Float16, (unsigned short)raw);
 }
 
-// Position arrays in LDS carry one pad word per block of D (index = block * (D+1) + offset): the scan threads
-// walk their blocks in step, D words apart -- without the pad every lane of a wave would hit the same bank.
-//
-// Block scans in three steps, so that the only serial part is a chain of fp64 adds:
-//   mb_block_max   one block per thread: M[blk] = max of the block                       (D reads)
-//   mb_block_pow   one position per lane: T[x] = 2^(v - M[blk]) as a DOUBLE              (the exp2s, all parallel)
-//   mb_block_sums  one block per thread: S[x] = suffix sums of T, then T[x] = prefix sums (in place)
-// A double keeps 2^-1000: a prefix or suffix that lies hundreds of bits below the block's largest entry -- a
-// window far from the row's bulk is made of exactly such parts -- still has full relative precision (fp32 sums
-// normalised by one block maximum underflow there; measured, tests/test_mobo.py rows 57+ of the [64,257] case).
-__device__ __forceinline__ void mb_block_max(const float *__restrict__ x, float *__restrict__ bmax, int nblk, int D) {
-    for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
-        const int o = blk * (D + 1);
-        float M = MB_NEG;
-#pragma unroll 8
-        for (int r = 0; r < D; ++r) {                               // (unrolled: the LDS reads of a batch go out together)
-            const float v = x[o + r];
-            M = (v > M) ? v : M;          // fmaxf(M, v) for a never-NaN M -- as fmaxf hipcc vectorised this reduction
-        }                                 // with a NaN test and an exec-mask exit per element
-        bmax[blk] = (M > 0.5f * MB_NEG) ? ceilf(M) : MB_NEG;      // an INTEGER reference: two blocks' sums are brought
-                                                                  // to a common scale by an exact ldexp (mb_window)
+// u = M + log2(s), M integer, s in (0.5, 1]; dead: (MB_DEADM, 0)
+__device__ __forceinline__ void mb_encode(float u, int &M, float &s) {
+    if (u > MB_DEADF) {
+        const float c = ceilf(u);
+        M = (int)c;
+        s = __builtin_amdgcn_exp2f(u - c);
+    } else {
+        M = MB_DEADM;
+        s = 0.f;
     }
-}
-__device__ __forceinline__ double mb_pow2(float f) {            // 2^f for f <= 0 as a double (0 below 2^-1000)
-    if (!(f > -1000.f)) return 0.0;
-    const float k = floorf(f);
-    return __builtin_ldexp((double)__builtin_amdgcn_exp2f(f - k), (int)k);
-}
-__device__ __forceinline__ float mb_log2(double s) {              // log2 of a double (MB_NEG for 0)
-    if (!(s > 0.0)) return MB_NEG;
-    int ex;
-    const double mant = __builtin_frexp(s, &ex);
-    return (float)ex + __builtin_amdgcn_logf((float)mant);
-}
-__device__ __forceinline__ void mb_block_sums(double *__restrict__ T, double *__restrict__ S, int nblk, int D) {
-    for (int blk = threadIdx.x; blk < nblk; blk += blockDim.x) {
-        const int o = blk * (D + 1);
-        double acc = 0.0;
-#pragma unroll 8
-        for (int r = D - 1; r >= 0; --r) { acc += T[o + r]; S[o + r] = acc; }
-        acc = 0.0;
-        int r = 0;
-        for (; r + 8 <= D; r += 8) {               // in place: read a batch, then write it
-            double t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = T[o + r + u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { acc += t[u]; T[o + r + u] = acc; }
-        }
-        for (; r < D; ++r) { acc += T[o + r]; T[o + r] = acc; }
-    }
-}
-// log2(2^M1 * S1 + 2^M2 * S2): the two parts of a window, each relative to its block's (integer) reference
-__device__ __forceinline__ float mb_window(float M1, double S1, float M2, double S2) {
-    const bool a = S1 > 0.0, b = S2 > 0.0;
-    if (!a && !b) return MB_NEG;
-    const float m = fmaxf(a ? M1 : MB_NEG, b ? M2 : MB_NEG);
-    const float d1 = a ? fmaxf(M1 - m, -2000.f) : 0.f, d2 = b ? fmaxf(M2 - m, -2000.f) : 0.f;   // integers <= 0
-    const double t = (a ? __builtin_ldexp(S1, (int)d1) : 0.0) + (b ? __builtin_ldexp(S2, (int)d2) : 0.0);
-    return m + mb_log2(t);
 }
 
-// One block per thread: position of the maximum of every prefix (ties: the LARGEST position) and of every
-// suffix (ties: the largest position as well), as offsets inside the block.
-// (`first`: the thread that takes block 0 -- the caller runs this scan on other waves than the block maxima that
-// share its phase, so the two serial scans of phase D go side by side)
-__device__ __forceinline__ void mb_scan_argmax(const float *__restrict__ x, unsigned short *__restrict__ ipre,
-                                               unsigned short *__restrict__ isuf, int nblk, int D, int first) {
-    const int nthr = (int)blockDim.x, t0 = ((int)threadIdx.x - first + nthr) % nthr;
-    for (int blk = t0; blk < nblk; blk += nthr) {
-        const int o = blk * (D + 1);
-        float m = x[o];
-        int im = 0;
-        ipre[o] = 0;
-#pragma unroll 8
-        for (int r = 1; r < D; ++r) {
-            if (x[o + r] >= m) { m = x[o + r]; im = r; }
-            ipre[o + r] = (unsigned short)im;
-        }
-        m = x[o + D - 1];
-        im = D - 1;
-        isuf[o + D - 1] = (unsigned short)im;
-#pragma unroll 8
-        for (int r = D - 2; r >= 0; --r) {
-            if (x[o + r] > m) { m = x[o + r]; im = r; }
-            isuf[o + r] = (unsigned short)im;
+// One window of D consecutive entries: Mw = max M, acc = sum ldexp(s, M - Mw) (so the sum is 2^Mw * acc, acc in
+// [0.5, D] unless every entry is dead), and -- WITH_V -- the largest v with the LARGEST index among equals.
+template <bool WITH_V>
+__device__ __forceinline__ void mb_window(const int *__restrict__ sM, const float *__restrict__ sS,
+                                          const float *__restrict__ sV, int D, int &Mw, float &acc, float &best,
+                                          int &qbest) {
+    Mw = MB_DEADM;
+    acc = 0.f;
+    best = MB_NEG;
+    qbest = 0;
+    int c = 0;
+    const int r = D & 7;
+    for (; c < r; ++c) {                            // the D % 8 lowest entries one by one, then groups of eight
+        const int m = sM[c];
+        const int Mn = Mw > m ? Mw : m;
+        acc = __builtin_ldexpf(acc, Mw - Mn) + __builtin_ldexpf(sS[c], m - Mn);
+        Mw = Mn;
+        if (WITH_V) {
+            const float v = sV[c];
+            if (v >= best) {
+                best = v;
+                qbest = c;
+            }
         }
     }
+    int cbest = -1;                                 // the LAST group whose maximum is the running maximum
+    for (; c < D; c += 8) {
+        int m[8];
+        float s[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            m[u] = sM[c + u];
+            s[u] = sS[c + u];
+            if (WITH_V) v[u] = sV[c + u];
+        }
+        int cm = m[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) cm = cm > m[u] ? cm : m[u];
+        const int Mn = Mw > cm ? Mw : cm;
+        acc = __builtin_ldexpf(acc, Mw - Mn);
+        Mw = Mn;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += __builtin_ldexpf(s[u], m[u] - Mw);
+        if (WITH_V) {                               // (v is never NaN: phase 1 replaces anything not above MB_DEADF)
+            float vm = v[0];
+#pragma unroll
+            for (int u = 1; u < 8; ++u) vm = __builtin_fmaxf(vm, v[u]);
+            if (vm >= best) {
+                best = vm;
+                cbest = c;
+            }
+        }
+    }
+    if (WITH_V && cbest >= 0) {                     // ties: the largest index
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (sV[cbest + u] == best) qbest = cbest + u;
+    }
+}
+
+__device__ __forceinline__ void mb_bounds(int I, int J, int D, int i, int &lo, int &hi) {
+    hi = J - (I - 1 - i);
+    const long long lo64 = (long long)J - (long long)(I - 1 - i) * D;
+    lo = (lo64 > i + 1) ? (int)lo64 : i + 1;
 }
 
 // Barrier for LDS hand-offs only: __syncthreads() also drains vmcnt, which would put the latency of the next
-// row's energy loads and of this row's result stores on every phase of the row loop.
+// row's loads and of this row's result stores on every row.
 __device__ __forceinline__ void mb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// every boundary position of this thread (j = tid, tid + nthr, ...), as a ROLLED loop: block and offset advance by
-// (nthr / D, nthr % D) without a division; the heavy phase bodies are instantiated once (unrolled x5 they spilled)
-#define MB_FOR_POS(...)                                                                        \
-    {                                                                                          \
-        int blk = blk0, r = r0;                                                                \
-        _Pragma("unroll 1") for (int j = tid; j < P; j += nthr) {                              \
-            const int x = blk * (D + 1) + r;                                                   \
-            __VA_ARGS__                                                                        \
-            r += rstep;                                                                        \
-            blk += bstep;                                                                      \
-            if (r >= D) { r -= D; ++blk; }                                                     \
-        }                                                                                      \
-    }
-constexpr int MB_NPOS = 5;     // boundary positions per thread (P <= 5 * 1024)
-
+// ---------------------------------------------------------------------------------------------------------
+// 1. L_i(k) for every (utterance, token, position); also refills the ring and clears the give-up words.
+//    grid (ceil(Ty/256), Tx, B) x 256 threads, one position k per thread, window (k, k+D] read from LDS.
+// ---------------------------------------------------------------------------------------------------------
 template <int VT>
-__global__ __launch_bounds__(MB_THREADS) void mobo_forward_kernel(MoboParams p) {
+__global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned long long ring_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int b = blockIdx.x;
-    const int P = p.P, D = p.D, nblk = P / D, PP = P + nblk;     // PP: padded array length
-    double *sT = reinterpret_cast<double *>(smem);  // 2^(v - block max), then the block prefix sums (in place)
-    double *sS = sT + PP;                           // block suffix sums
-    float *sE = reinterpret_cast<float *>(sS + PP); // e_i at boundary position j (energy of the token's last frame j-1)
-    float *sV = sE + PP;                            // delta_{i-1}(k) - L_i(k)
-    float *sA = sV + PP;                            // la_{i-1}; la_{i-1}(k) - L_i(k) between steps C and E; then la_i
-    float *sDl = sA + PP;                           // delta
-    float *sM = sDl + PP;                           // [nblk] block maxima (of e, then of U)
-    unsigned short *iP = reinterpret_cast<unsigned short *>(sM + nblk);     // [PP] prefix argmax of V
-    unsigned short *iS = iP + PP;                                           // [PP] suffix argmax of V
-
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, i = blockIdx.y, k0 = blockIdx.x * 256;
+    {   // housekeeping spread over the whole grid
+        const unsigned long long nthr = (unsigned long long)gridDim.x * gridDim.y * gridDim.z * 256ull;
+        const unsigned long long gid = (((unsigned long long)b * gridDim.y + i) * gridDim.x + blockIdx.x) * 256ull + tid;
+        for (unsigned long long w = gid; w < ring_words; w += nthr) p.ring[w] = MB_FILL;
+        if (gid < (unsigned long long)p.B) p.failw[gid] = 0;
+    }
+    const int D = p.D;
     int I = p.t_xs[b], J = p.t_ys[b];
     I = I > p.Tx ? p.Tx : I;
     J = J > p.Ty ? p.Ty : J;
     const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
-    if (!ok) {                                     // infeasible: no segmentation exists
-        if (tid == 0) atomicOr(p.status, ALIGNER_ST_BAD_LENGTHS);
-        for (int i = tid; i < p.Tx; i += nthr) {
-            p.boundaries[(size_t)b * p.Tx + i] = 0;
-            if (p.durations) p.durations[(size_t)b * p.Tx + i] = 0;
+    const int k = k0 + tid;
+    const size_t rowoff = ((size_t)b * p.Tx + i) * p.Ty;
+    if (!ok || i >= I) {                              // nothing to search here: only the padding of log_alpha
+        if (p.log_alpha && k < p.Ty) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+        return;
+    }
+    int lo, hi;
+    mb_bounds(I, J, D, i, lo, hi);
+    // positions the previous row can occupy (the only k whose normaliser is ever used)
+    int klo = 0, khi = 0;
+    if (i > 0) {
+        mb_bounds(I, J, D, i - 1, klo, khi);
+        const long long reach = (long long)i * D;
+        if (khi > reach) khi = (int)reach;
+    }
+    if (k0 > khi || k0 + 255 < klo) {                 // the whole block is outside the band
+        if (k < p.Ty) {
+            p.Lw[rowoff + k] = MB_NEG;
+            if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
         }
-        if (p.log_alpha)
-            for (size_t n = tid; n < (size_t)p.Tx * p.Ty; n += nthr) p.log_alpha[(size_t)b * p.Tx * p.Ty + n] = -__builtin_huge_valf();
+        return;
+    }
+    int *sM = reinterpret_cast<int *>(smem);
+    float *sS = reinterpret_cast<float *>(sM + 256 + D);
+    // entries x = 0 .. 255+D-1 stand for boundary positions m = k0+1+x, i.e. frames m-1
+    for (int x = tid; x < 256 + D; x += 256) {
+        const int m = k0 + 1 + x;
+        float e2 = MB_NEG;
+        if (m >= lo && m <= hi) e2 = mb_value<VT>(mb_load_raw<VT>(p.e, rowoff + (m - 1))) * MB_LOG2E;
+        int M;
+        float s;
+        mb_encode(e2, M, s);
+        sM[x] = M;
+        sS[x] = s;
+    }
+    __syncthreads();
+    if (k >= p.Ty) return;
+    float L = MB_NEG;
+    if (k < J && k >= klo && k <= khi) {
+        int Mw, qb;
+        float acc, best;
+        mb_window<false>(sM + tid, sS + tid, nullptr, D, Mw, acc, best, qb);
+        if (acc > 0.f) L = (float)Mw + __builtin_amdgcn_logf(acc);
+    }
+    p.Lw[rowoff + k] = L;
+    if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 2. The chain.  Block b*S + s = segment s of utterance b: positions [a, a+n) of its J+1 boundary positions.
+//    LDS: two buffers (row parity) of (M, s, v) for the segment's positions, preceded by the D halo entries
+//    that belong to the segment before -- one barrier per row.  NP positions per thread (j = a + tid + q*T).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mb_ring_store(unsigned *p, unsigned v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned mb_ring_load(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what the two forms of the chain kernel share: one position of phase 1 / phase 2
+struct MbSeg {
+    int a, bnd, D, J, W;
+    bool has_next;
+    int *sM;
+    float *sS, *sV;
+    unsigned *ring_out;
+};
+__device__ __forceinline__ void mb_phase1(const MbSeg &g, int i, int bo, int k, float la, float de, float Lraw) {
+    const float L = (k < g.J) ? Lraw : MB_NEG;     // the step out of J does not exist
+    const bool live = L > MB_DEADF;
+    const float u = (live && la > MB_DEADF) ? la - L : MB_NEG;
+    float v = (live && de > MB_DEADF) ? de - L : MB_NEG;
+    v = (v > MB_DEADF) ? v : MB_NEG;
+    int M;
+    float s;
+    mb_encode(u, M, s);
+    const int x = bo + g.D + (k - g.a);
+    g.sM[x] = M;
+    g.sS[x] = s;
+    g.sV[x] = v;
+    if (g.has_next && k >= g.bnd - g.D) {
+        unsigned *r = g.ring_out + (size_t)i * 3 * g.D + (k - (g.bnd - g.D));
+        mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
+        mb_ring_store(r + g.D, __builtin_bit_cast(unsigned, s));
+        mb_ring_store(r + 2 * g.D, __builtin_bit_cast(unsigned, v));
+    }
+}
+__device__ __forceinline__ void mb_phase2(const MbSeg &g, int bo, int j, int lo, int hi, float ev, float &lav, float &dev,
+                                          int &dur) {
+    lav = MB_NEG;
+    dev = MB_NEG;
+    dur = 0;
+    if (j >= lo && j <= hi) {
+        int Mw, qb;
+        float acc, best;
+        const int x = bo + (j - g.a);
+        mb_window<true>(g.sM + x, g.sS + x, g.sV + x, g.D, Mw, acc, best, qb);
+        if (acc > 0.f && ev > MB_DEADF) lav = ev + ((float)Mw + __builtin_amdgcn_logf(acc));
+        if (best > MB_DEADF && ev > MB_DEADF) {
+            dev = ev + best;
+            dur = g.D - qb;
+        }
+        lav = (lav > MB_DEADF) ? lav : MB_NEG;
+        dev = (dev > MB_DEADF) ? dev : MB_NEG;
+        if (!(dev > MB_DEADF)) dur = 0;
+    }
+}
+
+// MULTI = false: at most one position per thread -- the form of a split utterance (a segment per CU): the state
+//   of a position lives in registers and the next row's operands (energy, normaliser, halo) are in flight while
+//   this row is computed.  MULTI = true: any number of positions per thread, state in LDS, operands loaded where
+//   they are used -- the form of a large batch, where a CU's many waves hide the latency.
+template <int VT, bool MULTI>
+__global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int b = blockIdx.x / p.S, sg = blockIdx.x - b * p.S;
+    const int D = p.D;
+    int I = p.t_xs[b], J = p.t_ys[b];
+    I = I > p.Tx ? p.Tx : I;
+    J = J > p.Ty ? p.Ty : J;
+    const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
+    if (!ok) {                                     // infeasible: no segmentation exists (outputs: the other kernels)
+        if (sg == 0 && tid == 0) atomicOr(p.status, ALIGNER_ST_BAD_LENGTHS);
+        return;
+    }
+    // this utterance's segments: every one but the last holds n >= D positions, so a halo has one source
+    const int P = J + 1;
+    int Sb = P / D;
+    Sb = Sb < 1 ? 1 : (Sb > p.S ? p.S : Sb);
+    const int n = (P + Sb - 1) / Sb;
+    const int a = sg * n;
+    if (sg >= Sb || a >= P) return;
+    MbSeg g;
+    g.a = a;
+    g.bnd = (a + n < P) ? a + n : P;
+    g.D = D;
+    g.J = J;
+    g.W = p.nmax + D;                              // entries per buffer
+    g.has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
+    g.sM = reinterpret_cast<int *>(smem);
+    g.sS = reinterpret_cast<float *>(g.sM + 2 * g.W);
+    g.sV = g.sS + 2 * g.W;
+    float *sLa = g.sV + 2 * g.W, *sDe = sLa + p.nmax;     // MULTI only
+    const int bnd = g.bnd, W = g.W;
+    for (int h = tid; h < D; h += T) {             // positions before the utterance's start (segment 0 keeps these)
+        g.sM[h] = MB_DEADM;  g.sM[W + h] = MB_DEADM;
+        g.sS[h] = 0.f;       g.sS[W + h] = 0.f;
+        g.sV[h] = MB_NEG;    g.sV[W + h] = MB_NEG;
+    }
+    const int j1 = a + tid;                        // !MULTI: this thread's position
+    float la = (j1 == 0) ? 0.f : MB_NEG, de = la;  // P(b_-1 = 0) = 1
+    if (MULTI)
+        for (int j = j1; j < bnd; j += T) {
+            sLa[j - a] = (j == 0) ? 0.f : MB_NEG;
+            sDe[j - a] = (j == 0) ? 0.f : MB_NEG;
+        }
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
+    g.ring_out = p.ring + ((size_t)b * (p.S - 1) + (g.has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
+    const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
+    const bool polls = sg > 0 && tid < D;
+
+    unsigned e_nx = 0, h_nx[3] = {0, 0, 0};
+    float L_nx = MB_NEG;
+    auto issue = [&](int i) {                      // row i's operands, in flight while row i-1 is computed
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        if (!MULTI) {
+            const int j = j1 < 1 ? 1 : (j1 > J ? J : j1);
+            const int k = j1 > J - 1 ? J - 1 : j1;
+            e_nx = mb_load_raw<VT>(p.e, ro + (j - 1));
+            L_nx = p.Lw[ro + k];
+        }
+        if (polls) {
+            const unsigned *r = ring_in + (size_t)i * 3 * D + tid;
+            h_nx[0] = mb_ring_load(r);
+            h_nx[1] = mb_ring_load(r + D);
+            h_nx[2] = mb_ring_load(r + 2 * D);
+        }
+    };
+    issue(0);
+    bool gave_up = false;
+    bool prev_active = (sg == 0);                 // row -1: position 0 holds P(b_-1 = 0) = 1
+    for (int i = 0; i < I; ++i) {
+        int lo, hi;
+        mb_bounds(I, J, D, i, lo, hi);
+        const long long reach = (long long)(i + 1) * D;
+        const int hi2 = hi < reach ? hi : (int)reach;
+        const bool active = lo < bnd && hi2 >= a && lo <= hi2;      // some position of the segment is reachable
+        const unsigned e_c = e_nx, h_c0 = h_nx[0], h_c1 = h_nx[1], h_c2 = h_nx[2];
+        const float L_c = L_nx;
+        if (i + 1 < I) issue(i + 1);
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        const int bo = (i & 1) * W;
+        // phase 1 concerns the PREVIOUS row's states: the segment's last D entries are owed to the next segment as
+        // long as row i-1 had a reachable position here, whether or not row i has one
+        if (active || prev_active) {
+            // ---- phase 1: u = la_{i-1}(k) - L_i(k), v = delta_{i-1}(k) - L_i(k) for the segment's own positions ----
+            if (!MULTI) {
+                if (j1 < bnd) mb_phase1(g, i, bo, j1, la, de, L_c);
+            } else {
+#pragma unroll 1
+                for (int k = j1; k < bnd; k += T)
+                    mb_phase1(g, i, bo, k, sLa[k - a], sDe[k - a], p.Lw[ro + (k > J - 1 ? J - 1 : k)]);
+            }
+        } else if (g.has_next) {
+            for (int h = tid; h < D; h += T) {
+                unsigned *r = g.ring_out + (size_t)i * 3 * D + h;
+                mb_ring_store(r, __builtin_bit_cast(unsigned, (float)MB_DEADM));
+                mb_ring_store(r + D, 0u);
+                mb_ring_store(r + 2 * D, __builtin_bit_cast(unsigned, MB_NEG));
+            }
+        }
+        if (active) {
+            // ---- the D entries before the segment: the previous segment's row i (its words are their own flags) ----
+            if (sg > 0) {
+#pragma unroll 1
+                for (int h = tid; h < D; h += T) {
+                    const unsigned *r = ring_in + (size_t)i * 3 * D + h;
+                    unsigned w0, w1, w2;
+                    if (h == tid) { w0 = h_c0; w1 = h_c1; w2 = h_c2; }
+                    else { w0 = mb_ring_load(r); w1 = mb_ring_load(r + D); w2 = mb_ring_load(r + 2 * D); }
+                    int spins = 0;
+                    while ((w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL) && !gave_up) {
+                        __builtin_amdgcn_s_sleep(4);
+                        w0 = mb_ring_load(r);
+                        w1 = mb_ring_load(r + D);
+                        w2 = mb_ring_load(r + 2 * D);
+                        if (++spins > p.spin_limit) gave_up = true;
+                    }
+                    const bool bad = (w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL);
+                    g.sM[bo + h] = bad ? MB_DEADM : (int)__builtin_bit_cast(float, w0);
+                    g.sS[bo + h] = bad ? 0.f : __builtin_bit_cast(float, w1);
+                    g.sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, w2);
+                }
+            }
+            mb_lds_barrier();
+            // ---- phase 2: the windows [j-D, j) ----
+#pragma unroll 1
+            for (int j = j1; j < bnd; j += T) {
+                float ev;
+                if (!MULTI) ev = mb_value<VT>(e_c) * MB_LOG2E;
+                else ev = (j >= lo && j <= hi) ? mb_value<VT>(mb_load_raw<VT>(p.e, ro + (j - 1))) * MB_LOG2E : MB_NEG;
+                float lav, dev;
+                int dur;
+                mb_phase2(g, bo, j, lo, hi, ev, lav, dev, dur);
+                if (!MULTI) { la = lav; de = dev; }
+                else { sLa[j - a] = lav; sDe[j - a] = dev; }
+                backb[(size_t)i * (p.Ty + 1) + j] = (unsigned short)dur;
+                if (p.log_alpha && j >= 1)
+                    p.log_alpha[ro + (j - 1)] = (lav > MB_DEADF) ? lav * MB_LN2 : -__builtin_huge_valf();
+                if (i == I - 1 && j == J && p.map_score)
+                    p.map_score[b] = (dev > MB_DEADF) ? dev * MB_LN2 : -__builtin_huge_valf();
+                if (!MULTI) break;
+            }
+        } else {
+            // ---- no reachable position in this row: everything is "log 0" ----
+            la = MB_NEG;
+            de = MB_NEG;
+#pragma unroll 1
+            for (int j = j1; j < bnd; j += T) {
+                if (MULTI) { sLa[j - a] = MB_NEG; sDe[j - a] = MB_NEG; }
+                if (p.log_alpha && j >= 1) p.log_alpha[ro + (j - 1)] = -__builtin_huge_valf();
+                if (i == I - 1 && j == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+            }
+        }
+        prev_active = active;
+    }
+    if (gave_up) {                                 // the segment before never delivered: say so, loudly
+        atomicOr(p.status, ALIGNER_ST_INTERNAL);
+        p.failw[b] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 3. Backtrack of the MAP sequence: RB rows at a time.  After t steps from position j the walk is within
+//    [j - t*D, j - t], so the durations of the batch's rows over those windows are fetched in one go.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mobo_backtrack_kernel(MoboParams p, int RB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_j, s_bad;
+    __shared__ int s_b[64], s_d[64];
+    unsigned short *win = reinterpret_cast<unsigned short *>(smem);
+    const int tid = threadIdx.x, b = blockIdx.x, D = p.D;
+    int I = p.t_xs[b], J = p.t_ys[b];
+    I = I > p.Tx ? p.Tx : I;
+    J = J > p.Ty ? p.Ty : J;
+    const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
+    int *bo = p.boundaries + (size_t)b * p.Tx;
+    int *du = p.durations ? p.durations + (size_t)b * p.Tx : nullptr;
+    if (!ok || p.failw[b]) {
+        for (int i = tid; i < p.Tx; i += 256) {
+            bo[i] = 0;
+            if (du) du[i] = 0;
+        }
         if (p.map_score && tid == 0) p.map_score[b] = -__builtin_huge_valf();
         return;
     }
-    // this thread's boundary positions (the same for every token row): j, its block, offset and padded index
-    int pj[MB_NPOS], pb[MB_NPOS], pr[MB_NPOS];
-#pragma unroll
-    for (int n = 0; n < MB_NPOS; ++n) {
-        const int j = tid + n * nthr;
-        pj[n] = j < P ? j : -1;
-        pb[n] = j / D;
-        pr[n] = j - pb[n] * D;
+    for (int i = I + tid; i < p.Tx; i += 256) {
+        bo[i] = J;
+        if (du) du[i] = 0;
     }
-#pragma unroll
-    for (int n = 0; n < MB_NPOS; ++n)
-        if (pj[n] >= 0) {
-            const int x = pb[n] * (D + 1) + pr[n];
-            sA[x] = (pj[n] == 0) ? 0.f : MB_NEG;   // P(b_-1 = 0) = 1
-            sDl[x] = (pj[n] == 0) ? 0.f : MB_NEG;
-        }
+    const unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
+    const int ws = (RB - 1) * D + 1;               // entries kept per row of a batch
+    if (tid == 0) { s_j = J; s_bad = 0; }
     __syncthreads();
-    unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
-    const int blk0 = tid / D, r0 = tid - blk0 * D, bstep = nthr / D, rstep = nthr - bstep * D;
-    unsigned enext[MB_NPOS];                       // raw bits of the next row's energies (clamped index: no branch)
-#pragma unroll
-    for (int n = 0; n < MB_NPOS; ++n) {
-        const int jj = pj[n] < 1 ? 1 : (pj[n] > J ? J : pj[n]);
-        enext[n] = mb_load_raw<VT>(p.e, (size_t)b * p.Tx * p.Ty + (jj - 1));
-    }
-    for (int i = 0; i < I; ++i) {
-        const int hi = J - (I - 1 - i);
-        const long long lo64 = (long long)J - (long long)(I - 1 - i) * D;
-        const int lo = (lo64 > i + 1) ? (int)lo64 : i + 1;
-        // ---- A: this token's energies at the feasible boundary positions, base-2 (fetched during the previous
-        //         row: the loads of row i+1 are in flight while row i is computed) ----
-        const size_t rowoff = ((size_t)b * p.Tx + i) * p.Ty;
-#pragma unroll
-        for (int n = 0; n < MB_NPOS; ++n)
-            if (pj[n] >= 0) {
-                const int j = pj[n];
-                sE[pb[n] * (D + 1) + pr[n]] = (j >= lo && j <= hi) ? mb_value<VT>(enext[n]) * MB_LOG2E : MB_NEG;
-            }
-        mb_lds_barrier();
-        if (i + 1 < I) {
-            const size_t nextoff = rowoff + p.Ty;
-#pragma unroll
-            for (int n = 0; n < MB_NPOS; ++n) {
-                const int jj = pj[n] < 1 ? 1 : (pj[n] > J ? J : pj[n]);
-                enext[n] = mb_load_raw<VT>(p.e, nextoff + (jj - 1));
-            }
+    for (int i = I - 1; i >= 0; i -= RB) {
+        const int nb = (i + 1 < RB) ? i + 1 : RB;
+        const int j = s_j;
+        for (int t = 0; t < nb; ++t) {              // row i-t: positions j - t*D .. j - t
+            const int base = j - t * D, cnt = t * (D - 1) + 1;
+            const unsigned short *src = backb + (size_t)(i - t) * (p.Ty + 1);
+            for (int c = tid; c < cnt; c += 256) win[t * ws + c] = (base + c >= 0) ? src[base + c] : (unsigned short)0;
         }
-        // ---- B: block scans of e ----
-        mb_block_max(sE, sM, nblk, D);
-        mb_lds_barrier();
-        MB_FOR_POS({ sT[x] = mb_pow2(sE[x] - sM[blk]); });
-        mb_lds_barrier();
-        mb_block_sums(sT, sS, nblk, D);
-        mb_lds_barrier();
-        // ---- C: normaliser of the step out of k: positions (k, k+D] = rest of k's block + head of the next.
-        //         u = la_{i-1}(k) - L replaces la_{i-1}(k) in place (a lane only ever reads its own entry of sA) ----
-        MB_FOR_POS({
-            const double S1 = (r + 1 < D) ? sS[x + 1] : 0.0;
-            const double S2 = (blk + 1 < nblk) ? sT[(blk + 1) * (D + 1) + r] : 0.0;
-            const float L = mb_window(sM[blk], S1, (blk + 1 < nblk) ? sM[blk + 1] : MB_NEG, S2);
-            const bool live = L > 0.5f * MB_NEG;
-            const float a = sA[x], d = sDl[x];
-            sA[x] = (live && a > 0.5f * MB_NEG) ? a - L : MB_NEG;
-            sV[x] = (live && d > 0.5f * MB_NEG) ? d - L : MB_NEG;
-        });
-        mb_lds_barrier();
-        // ---- D: block scans of U (sums) and V (argmax) ----
-        mb_block_max(sA, sM, nblk, D);
-        mb_scan_argmax(sV, iP, iS, nblk, D, (nthr >= 2 * nblk) ? (nthr / 2) & ~63 : 0);
-        mb_lds_barrier();
-        MB_FOR_POS({ sT[x] = mb_pow2(sA[x] - sM[blk]); });
-        mb_lds_barrier();
-        mb_block_sums(sT, sS, nblk, D);
-        mb_lds_barrier();
-        // ---- E: window [j-D, j) = tail of the previous block + head of j's block ----
-        MB_FOR_POS({
-            float la = MB_NEG, de = MB_NEG;
-            int dur = 0;
-            if (j >= lo && j <= hi) {
-                const int xp = (blk - 1) * (D + 1) + r;              // same offset, previous block
-                const double S1 = (blk >= 1) ? sS[xp] : 0.0;
-                const double S2 = (r >= 1) ? sT[x - 1] : 0.0;
-                const float w = mb_window((blk >= 1) ? sM[blk - 1] : MB_NEG, S1, sM[blk], S2);
-                if (w > 0.5f * MB_NEG) la = sE[x] + w;
-                // max-product twin: best previous boundary, the larger position on a tie
-                int kb = -1;
-                float vb = MB_NEG;
-                if (blk >= 1) {
-                    const int rr = iS[xp];
-                    kb = (blk - 1) * D + rr;
-                    vb = sV[(blk - 1) * (D + 1) + rr];
-                }
-                if (r >= 1) {
-                    const int rr = iP[x - 1];
-                    const float v2 = sV[blk * (D + 1) + rr];
-                    if (v2 >= vb) { kb = blk * D + rr; vb = v2; }
-                }
-                if (kb >= 0 && vb > 0.5f * MB_NEG) { de = sE[x] + vb; dur = j - kb; }
+        __syncthreads();
+        if (tid == 0) {
+            int jj = j;
+            for (int t = 0; t < nb; ++t) {
+                const int d = win[t * ws + (jj - (j - t * D))];
+                s_b[t] = jj;
+                s_d[t] = d;
+                if (d < 1 || d > D || d > jj) { s_bad = 1; jj = 0; break; }
+                jj -= d;
             }
-            if (j <= p.Ty) backb[(size_t)i * (p.Ty + 1) + j] = (unsigned short)dur;
-            if (p.log_alpha && j >= 1 && j <= p.Ty)
-                p.log_alpha[rowoff + (j - 1)] = (la > 0.5f * MB_NEG) ? la * MB_LN2 : -__builtin_huge_valf();
-            sA[x] = la;                                // (the windows read the scans, not these)
-            sDl[x] = de;
-        });
-        mb_lds_barrier();
-    }
-    if (p.log_alpha)       // rows past the utterance's own text
-        for (size_t n = (size_t)I * p.Ty + tid; n < (size_t)p.Tx * p.Ty; n += nthr)
-            p.log_alpha[(size_t)b * p.Tx * p.Ty + n] = -__builtin_huge_valf();
-    __threadfence_block();
-    __syncthreads();
-    // ---- backtrack of the MAP sequence: I dependent look-ups ----
-    if (tid == 0) {
-        const float sc = sDl[(J / D) * (D + 1) + (J % D)];
-        if (p.map_score) p.map_score[b] = (sc > 0.5f * MB_NEG) ? sc * MB_LN2 : -__builtin_huge_valf();
-        int j = J;
-        for (int i = I - 1; i >= 0; --i) {
-            const int d = backb[(size_t)i * (p.Ty + 1) + j];
-            p.boundaries[(size_t)b * p.Tx + i] = j;
-            if (p.durations) p.durations[(size_t)b * p.Tx + i] = d;
-            j -= d;
+            s_j = jj;
         }
-        if (j != 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+        __syncthreads();
+        if (s_bad) break;
+        if (tid < nb) {
+            bo[i - tid] = s_b[tid];
+            if (du) du[i - tid] = s_d[tid];
+        }
+        __syncthreads();
     }
-    for (int i = I + tid; i < p.Tx; i += nthr) {
-        p.boundaries[(size_t)b * p.Tx + i] = J;
-        if (p.durations) p.durations[(size_t)b * p.Tx + i] = 0;
-    }
+    if (tid == 0 && (s_bad || s_j != 0)) atomicOr(p.status, ALIGNER_ST_INTERNAL);
 }
 
 // gamma[i,y] = P(b_{i-1} <= y) - P(b_i <= y) from the forward variables: one workgroup per (utterance, token),
@@ -374,13 +555,55 @@ __global__ __launch_bounds__(256) void mobo_gamma_kernel(const float *__restrict
     }
 }
 
-struct MoboWs { size_t status_off, back_off, total; };
-static MoboWs mobo_ws(int B, int Tx, int Ty) {
-    MoboWs L;
-    L.status_off = 0;
-    L.back_off = 256;
-    L.total = align_up(L.back_off + (size_t)B * Tx * (Ty + 1) * sizeof(unsigned short), 256);
-    return L;
+// ---------------------------------------------------------------------------------------------------------
+// launch plan: D, segments per utterance, positions per segment, threads, workspace layout
+// ---------------------------------------------------------------------------------------------------------
+struct MoboPlan {
+    int D, S, nmax, NP, T, RB;
+    size_t lds, bt_lds, ring_words;
+    size_t status_off, fail_off, L_off, back_off, ring_off, total;
+};
+
+static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool quiet) {
+    const int D = max_duration > Ty ? Ty : max_duration;
+    const int P = Ty + 1;
+    const int cu = device_cu_count();
+    const int lds_limit = device_lds_limit();
+    const int smax = P / D < 1 ? 1 : P / D;        // a segment (but the last) holds at least D positions
+    int S = cu / (B < 1 ? 1 : B);
+    S = S < 1 ? 1 : S;
+    S = S > smax ? smax : S;
+    const int swave = (P + 63) / 64;               // ... and a wave's worth of them
+    S = S > swave ? swave : S;
+    int nmax = 0;
+    size_t lds = 0;
+    for (;; ++S) {
+        const int n1 = (P + S - 1) / S, n2 = (2 * D < P) ? 2 * D : P;
+        nmax = n1 > n2 ? n1 : n2;
+        lds = (size_t)2 * 3 * 4 * ((size_t)nmax + D) + (nmax > 1024 ? (size_t)8 * nmax : 0);
+        if (lds <= (size_t)lds_limit) break;
+        if (S >= smax)
+            return quiet ? ALIGNER_EDOM
+                         : fail(ALIGNER_EDOM, "Ty=%d with max_duration=%d needs %zu bytes of LDS per segment (limit %d)", Ty,
+                                D, lds, lds_limit);
+    }
+    pl.D = D;
+    pl.S = S;
+    pl.nmax = nmax;
+    pl.NP = nmax <= 1024 ? 1 : 2;                  // 1: a position per thread (registers); 2: "several" (LDS, loops)
+    pl.T = nmax <= 1024 ? (nmax + 63) / 64 * 64 : 1024;
+    pl.lds = lds;
+    int RB = (int)std::sqrt(32768.0 / D);
+    pl.RB = RB < 1 ? 1 : (RB > 32 ? 32 : RB);
+    pl.bt_lds = (size_t)pl.RB * ((size_t)(pl.RB - 1) * D + 1) * sizeof(unsigned short);
+    pl.ring_words = (size_t)B * (S - 1) * Tx * 3 * D;
+    pl.status_off = 0;
+    pl.fail_off = 256;
+    pl.L_off = align_up(pl.fail_off + (size_t)B * sizeof(int), 256);
+    pl.back_off = align_up(pl.L_off + (size_t)B * Tx * Ty * sizeof(float), 256);
+    pl.ring_off = align_up(pl.back_off + (size_t)B * Tx * (Ty + 1) * sizeof(unsigned short), 256);
+    pl.total = align_up(pl.ring_off + pl.ring_words * sizeof(unsigned), 256);
+    return ALIGNER_OK;
 }
 
 }  // namespace aligner
@@ -389,9 +612,19 @@ using namespace aligner;
 
 extern "C" {
 
+size_t aligner_boundary_search_workspace_bytes_ex(int B, int Tx, int Ty, int max_duration) {
+    if (B < 0 || Tx < 1 || Ty < 1 || max_duration < 1) return 0;
+    MoboPlan pl;
+    if (mobo_plan(B, Tx, Ty, max_duration, pl, true) != ALIGNER_OK) return 0;
+    return pl.total;
+}
+
 size_t aligner_boundary_search_workspace_bytes(int B, int Tx, int Ty) {
     if (B < 0 || Tx < 1 || Ty < 1) return 0;
-    return mobo_ws(B, Tx, Ty).total;
+    // whatever the window: the ring holds (S-1)*D <= Ty positions of 3 words per token row
+    const size_t fixed = 256 + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B * Tx * Ty * sizeof(float), 256) +
+                         align_up((size_t)B * Tx * (Ty + 1) * sizeof(unsigned short), 256);
+    return fixed + align_up((size_t)B * Tx * 3 * ((size_t)Ty + 1) * sizeof(unsigned), 256) + 256;
 }
 
 int aligner_boundary_search(const void *energies, int energy_dtype, const int32_t *t_xs, const int32_t *t_ys,
@@ -406,32 +639,49 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
     if (gamma_out && !log_alpha_out) return fail(ALIGNER_EINVAL, "gamma needs the log_alpha buffer as well");
     if (B == 0) return ALIGNER_OK;
     if (B > 65535 || Tx > 65535) return fail(ALIGNER_EDOM, "grid too large");
-    const int D = max_duration > Ty ? Ty : max_duration;
-    if (D > 65535) return fail(ALIGNER_EDOM, "max_duration %d too large", max_duration);
-    const MoboWs L = mobo_ws(B, Tx, Ty);
-    if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
-    const int P = (Ty + 1 + D - 1) / D * D;
-    const int nblk = P / D;
-    const size_t PP = (size_t)P + nblk;            // one pad word per block
-    const size_t lds = 2 * PP * sizeof(double) + 4 * PP * sizeof(float) + (size_t)nblk * sizeof(float) +
-                       2 * PP * sizeof(unsigned short) + 16;
-    if (P > MB_NPOS * 1024) return fail(ALIGNER_EDOM, "Ty=%d exceeds %d boundary positions", Ty, MB_NPOS * 1024);
-    if (lds > (size_t)device_lds_limit())
-        return fail(ALIGNER_EDOM, "Ty=%d with max_duration=%d needs %zu bytes of LDS (limit %d)", Ty, D, lds, device_lds_limit());
+    if ((max_duration > Ty ? Ty : max_duration) > 65535) return fail(ALIGNER_EDOM, "max_duration %d too large", max_duration);
+    MoboPlan pl;
+    const int prc = mobo_plan(B, Tx, Ty, max_duration, pl, false);
+    if (prc) return prc;
+    if ((long long)B * pl.S > 0x7fffffffLL) return fail(ALIGNER_EDOM, "grid too large");
+    if (workspace_bytes < pl.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, pl.total);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    MoboParams p{energies, vt, t_xs, t_ys, log_alpha_out, boundaries_out, durations_out, map_score_out,
-                 reinterpret_cast<unsigned short *>(ws + L.back_off), reinterpret_cast<int *>(ws + L.status_off), B, Tx, Ty,
-                 D, P};
-    const int threads = P >= 1024 ? 1024 : (P + 63) / 64 * 64;
-    auto launch = [&](auto kern) -> int {
-        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
-        hipLaunchKernelGGL(kern, dim3(B), dim3(threads), lds, s, p);
+    MoboParams p{energies, t_xs, t_ys, log_alpha_out, boundaries_out, durations_out, map_score_out,
+                 reinterpret_cast<float *>(ws + pl.L_off), reinterpret_cast<unsigned short *>(ws + pl.back_off),
+                 reinterpret_cast<unsigned *>(ws + pl.ring_off), reinterpret_cast<int *>(ws + pl.fail_off),
+                 reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, pl.D, pl.S, pl.nmax,
+                 g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
+    {   // 1. normalisers (+ ring refill)
+        const size_t nlds = (size_t)(256 + pl.D) * 8;
+        if (nlds > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "max_duration %d needs %zu bytes of LDS", pl.D, nlds);
+        const dim3 grid((Ty + 255) / 256, Tx, B);
+        auto launch = [&](auto kern) -> int {
+            ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), nlds));
+            hipLaunchKernelGGL(kern, grid, dim3(256), nlds, s, p, (unsigned long long)pl.ring_words);
+            ALIGNER_HIP_CHECK(hipGetLastError());
+            return ALIGNER_OK;
+        };
+        const int rc = vt == 0 ? launch(mobo_norm_kernel<0>) : vt == 1 ? launch(mobo_norm_kernel<1>) : launch(mobo_norm_kernel<2>);
+        if (rc) return rc;
+    }
+    {   // 2. the chain
+        auto launch = [&](auto kern) -> int {
+            ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), pl.lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)B * pl.S), dim3(pl.T), pl.lds, s, p);
+            ALIGNER_HIP_CHECK(hipGetLastError());
+            return ALIGNER_OK;
+        };
+        int rc;
+#define MB_LAUNCH_NP(VT_) (pl.NP == 1 ? launch(mobo_chain_kernel<VT_, false>) : launch(mobo_chain_kernel<VT_, true>))
+        rc = vt == 0 ? MB_LAUNCH_NP(0) : vt == 1 ? MB_LAUNCH_NP(1) : MB_LAUNCH_NP(2);
+        if (rc) return rc;
+    }
+    {   // 3. the MAP sequence
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(mobo_backtrack_kernel), pl.bt_lds));
+        hipLaunchKernelGGL(mobo_backtrack_kernel, dim3(B), dim3(256), pl.bt_lds, s, p, pl.RB);
         ALIGNER_HIP_CHECK(hipGetLastError());
-        return ALIGNER_OK;
-    };
-    const int rc = vt == 0 ? launch(mobo_forward_kernel<0>) : vt == 1 ? launch(mobo_forward_kernel<1>) : launch(mobo_forward_kernel<2>);
-    if (rc) return rc;
+    }
     if (gamma_out) {
         hipLaunchKernelGGL(mobo_gamma_kernel, dim3(Tx, B), dim3(256), 0, s, log_alpha_out, t_xs, t_ys, gamma_out, Tx, Ty);
         ALIGNER_HIP_CHECK(hipGetLastError());

@@ -51,7 +51,10 @@ def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor
     lib = _lib.load()
     if B > 0:
         with torch.cuda.device(dev):
-            ws = _workspaces.get(dev, lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty))
+            need = lib.aligner_boundary_search_workspace_bytes_ex(B, Tx, Ty, int(max_duration))
+            if need == 0:                   # shape outside the kernels' limits: let the call say why
+                need = 256
+            ws = _workspaces.get(dev, need)
             _lib.check(lib.aligner_boundary_search(
                 e.data_ptr(), _DT[e.dtype], tx.data_ptr(), ty.data_ptr(), int(max_duration), bnd.data_ptr(),
                 dur.data_ptr(), score.data_ptr(), None if la is None else la.data_ptr(),

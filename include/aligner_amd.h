@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ALIGNER_ABI_VERSION 2
+#define ALIGNER_ABI_VERSION 3
 
 /* error codes */
 #define ALIGNER_OK       0
@@ -183,7 +183,9 @@ void aligner_debug_set_stamps(void *stamps_dev);
 
 /* Development switches, process-wide (0/1; defaults from the environment variables ALIGNER_FWDSUM_ONE_WAVE /
  * ALIGNER_SOFTATTN_EXACT, read once at load): "fwdsum_one_wave" forces the one-sweeping-wave forward-sum
- * kernels, "softattn_exact" the exact-product similarity kernel.  ALIGNER_EINVAL for an unknown name. */
+ * kernels, "softattn_exact" the exact-product similarity kernel; "mobo_drop_segment" (a segment index, -1 = off)
+ * makes that position segment of every utterance withhold its rows from the next one, which then gives up after a
+ * short wait: the test of the boundary search's defined failure.  ALIGNER_EINVAL for an unknown name. */
 int aligner_debug_set_option(const char *name, int value);
 
 /*
@@ -309,12 +311,21 @@ int aligner_regulate_f32(const float *h_dev, const int32_t *durations_dev, float
  *   durations_out_dev  optional [B,Tx] int32; map_score_out_dev optional [B] fp32 (its log-probability)
  *   log_alpha_out_dev  optional [B,Tx,Ty] fp32: log P(b_i = j) at [i, j-1], -inf where impossible
  *   gamma_out_dev      optional [B,Tx,Ty] fp32 soft alignment P(b_{i-1} <= y < b_i); needs log_alpha_out_dev
- *   workspace_dev      aligner_boundary_search_workspace_bytes(B,Tx,Ty) bytes, first 256 zeroed once (status word
- *                      as for aligner_maxpath: ALIGNER_ST_BAD_LENGTHS for an utterance without any segmentation,
- *                      i.e. not t_x <= t_y <= t_x*max_duration; its outputs are 0 / -inf)
- * Ty is limited by LDS (about 4400 positions at max_duration 32); ALIGNER_EDOM beyond.
+ *   workspace_dev      aligner_boundary_search_workspace_bytes_ex(B,Tx,Ty,max_duration) bytes (the form without
+ *                      max_duration is an upper bound for every window), first 256 zeroed once (status word as for
+ *                      aligner_maxpath: ALIGNER_ST_BAD_LENGTHS for an utterance without any segmentation, i.e. not
+ *                      t_x <= t_y <= t_x*max_duration; its outputs are 0 / -inf).  It holds the normalisers
+ *                      [B,Tx,Ty] fp32, the per-(token, position) durations [B,Tx,Ty+1] u16 and the ring through
+ *                      which the position segments of an utterance hand their last max_duration entries on.
+ * Three launches: normalisers of every (utterance, token, position) on the whole chip; the token chain with an
+ * utterance's positions cut into segments, one workgroup each (as many as fit the CUs: [8,500,4000] runs 32 per
+ * utterance), a segment waiting only for the one before it -- ALIGNER_ST_INTERNAL and all-zero boundaries /
+ * durations for an utterance whose segment gave up waiting (only possible when other work keeps its predecessor
+ * off the GPU for seconds); the MAP backtrack.  Ty is limited to 8192 positions per segment and by LDS
+ * (24 bytes per position and per window entry); ALIGNER_EDOM beyond.
  */
 size_t aligner_boundary_search_workspace_bytes(int B, int Tx, int Ty);
+size_t aligner_boundary_search_workspace_bytes_ex(int B, int Tx, int Ty, int max_duration);
 int aligner_boundary_search(const void *energies_dev, int energy_dtype,
                             const int32_t *t_xs_dev, const int32_t *t_ys_dev, int max_duration,
                             int32_t *boundaries_out_dev, int32_t *durations_out_dev, float *map_score_out_dev,

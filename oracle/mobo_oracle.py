@@ -119,6 +119,82 @@ def boundary_search(e: np.ndarray, D: int):
                 durations=dur.astype(np.int32), map_score=float(de_prev[J]))
 
 
+def _lse_rows(w):
+    """logsumexp along the last axis of a 2-D array of windows (-inf for an all -inf window)."""
+    m = w.max(axis=1)
+    ok = np.isfinite(m)
+    out = np.full(w.shape[0], NEG)
+    if ok.any():
+        with np.errstate(invalid="ignore"):
+            out[ok] = m[ok] + np.log(np.exp(w[ok] - m[ok, None]).sum(axis=1))
+    return out
+
+
+def boundary_search_fast(e: np.ndarray, D: int):
+    """The same quantities as boundary_search() with every token row vectorised over the positions (numpy
+    sliding windows): affordable at the full BASELINE config-5 size [500, 4000].  tests/test_mobo.py checks it
+    against the plain loops above on moderate shapes before trusting it at sizes the loops cannot reach."""
+    from numpy.lib.stride_tricks import sliding_window_view as swv
+    e = np.asarray(e, np.float64)
+    I, J = e.shape
+    if not feasible(I, J, D):
+        raise ValueError(f"infeasible: need I <= J <= I*D (I={I}, J={J}, D={D})")
+    la_prev = np.full(J + 1, NEG)
+    la_prev[0] = 0.0
+    de_prev = la_prev.copy()
+    log_alpha = np.full((I, J), NEG)
+    back = np.zeros((I, J + 1), np.int64)
+    cdf_prev = np.ones(J)
+    gamma = np.zeros((I, J))
+    pos = np.arange(J + 1)
+    for i in range(I):
+        lo, hi = _bounds(I, J, D, i)
+        s = np.full(J + 1, NEG)
+        s[1:] = e[i]
+        sm = np.where((pos >= lo) & (pos <= hi), s, NEG)
+        # L[k] = lse sm[k+1 .. k+D], k = 0..J-1
+        spad = np.concatenate([sm[1:], np.full(D, NEG)])
+        L = np.full(J + 1, NEG)
+        L[:J] = _lse_rows(swv(spad, D)[:J])
+        used = np.isfinite(la_prev) | np.isfinite(de_prev)
+        L = np.where(used, L, NEG)
+        okL = np.isfinite(L)
+        with np.errstate(invalid="ignore"):
+            u = np.where(okL, la_prev - L, NEG)
+            v = np.where(okL, de_prev - L, NEG)
+        u = np.where(np.isnan(u), NEG, u)
+        v = np.where(np.isnan(v), NEG, v)
+        # windows k = j-D .. j-1 for j = 0..J  (k < 0: -inf)
+        uw = swv(np.concatenate([np.full(D, NEG), u]), D)[:J + 1]
+        vw = swv(np.concatenate([np.full(D, NEG), v]), D)[:J + 1]
+        feas = (pos >= lo) & (pos <= hi)
+        la = np.full(J + 1, NEG)
+        de = np.full(J + 1, NEG)
+        idx = np.nonzero(feas)[0]
+        la[idx] = s[idx] + _lse_rows(uw[idx])
+        vmax = vw[idx].max(axis=1)
+        # ties: the largest previous boundary = the LAST maximum of the window
+        last = D - 1 - np.argmax(vw[idx][:, ::-1], axis=1)
+        okv = np.isfinite(vmax)
+        de[idx[okv]] = s[idx[okv]] + vmax[okv]
+        back[i, idx[okv]] = idx[okv] - D + last[okv]
+        la = np.where(np.isnan(la), NEG, la)
+        log_alpha[i] = la[1:]
+        cdf = np.cumsum(np.exp(la[1:]))
+        cdf_i = np.concatenate([[0.0], cdf[:-1]])
+        gamma[i] = cdf_prev - cdf_i
+        cdf_prev = cdf_i
+        la_prev, de_prev = la, de
+    bnd = np.zeros(I, np.int64)
+    j = J
+    for i in range(I - 1, -1, -1):
+        bnd[i] = j
+        j = back[i, j]
+    dur = np.diff(np.concatenate([[0], bnd]))
+    return dict(log_alpha=log_alpha, gamma=gamma, boundaries=bnd.astype(np.int32),
+                durations=dur.astype(np.int32), map_score=float(de_prev[J]))
+
+
 def sequence_log_prob(e: np.ndarray, D: int, boundaries) -> float:
     """log-probability of one boundary sequence under the chain (-inf if it violates a constraint)."""
     e = np.asarray(e, np.float64)

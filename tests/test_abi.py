@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(built_lib):
 
 
 def test_abi_version_and_errors(built_lib):
-    assert built_lib.aligner_abi_version() == 2
+    assert built_lib.aligner_abi_version() == 3
     assert built_lib.aligner_maxpath_workspace_bytes(64, 200, 1000) > 64 * 32 * 256 * 4
     assert built_lib.aligner_maxpath_workspace_bytes(1, 0, 5) == 0
     # argument validation happens before any HIP call
