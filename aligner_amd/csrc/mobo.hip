@@ -57,8 +57,12 @@ struct MoboParams {
     unsigned short *back;     // workspace [B,Tx,Ty+1]: duration of token i when it ends at j
     unsigned *ring;           // workspace [B,S-1,Tx,3,D]: (M, s, v) of a segment's last D positions, row by row
     int *failw;               // workspace [B]: 1 = a segment of this utterance gave up waiting
+    unsigned *trash;          // workspace [B*S,1024] (+ slack): where lanes with nothing to store store
     int *status;              // workspace: ALIGNER_ST_* bits
     int B, Tx, Ty, D, S, nmax;
+    int bstride;              // entries per row of `back`: a multiple of 8 >= Ty + 1 (16-byte pieces in the backtrack)
+    int start_lag;            // rows a segment lets the one before it get ahead before it starts (see the chain kernel)
+    unsigned long long *stamps;  // development (aligner_debug_set_stamps): per block 16 words of phase cycle totals
     int drop_seg, spin_limit;  // testing (aligner_debug_set_option "mobo_drop_segment"): that segment publishes nothing
 };
 
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
             sDe[j - a] = (j == 0) ? 0.f : MB_NEG;
         }
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
+    unsigned short *backb = p.back + (size_t)b * p.Tx * p.bstride;
     g.ring_out = p.ring + ((size_t)b * (p.S - 1) + (g.has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
     const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
     const bool polls = sg > 0 && tid < D;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
                 mb_phase2(g, bo, j, lo, hi, ev, lav, dev, dur);
                 if (!MULTI) { la = lav; de = dev; }
                 else { sLa[j - a] = lav; sDe[j - a] = dev; }
-                backb[(size_t)i * (p.Ty + 1) + j] = (unsigned short)dur;
+                backb[(size_t)i * p.bstride + j] = (unsigned short)dur;
                 if (p.log_alpha && j >= 1)
                     p.log_alpha[ro + (j - 1)] = (lav > MB_DEADF) ? lav * MB_LN2 : -__builtin_huge_valf();
                 if (i == I - 1 && j == J && p.map_score)
@@ -449,6 +453,259 @@ __global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
     }
 }
 
+// The split form: one position per thread, everything a row needs in flight a row ahead.
+//
+// What paces a row here is not arithmetic but `s_waitcnt`: loads, stores and atomics retire through ONE counter
+// in issue order, and hipcc can only emit a counted wait (leave the N youngest operations in flight) when it can
+// prove N operations follow -- anything behind a branch counts as "maybe" and turns the wait into vmcnt(0), which
+// then also waits for the row's result stores to be acknowledged (measured: 4 500 cycles a row instead of ~1 200).
+// So the rows in which the segment has a reachable position run as one straight-line body: every lane issues every
+// load and store of the row, lanes with nothing to say address a trash area of the workspace, and the first use
+// of the prefetched operands waits behind exactly the stores issued after them.  Rows before / after that range
+// only hand "log 0" entries on.
+template <int VT, bool WANT_LA>
+__global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, T = blockDim.x;
+    const bool stamping = p.stamps != nullptr && tid == 0;
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_entry = 0, st_rt = 0, st_polls = 0;
+    if (stamping) { st_entry = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
+#define MB_STAMP(k_) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k_] += t_ - st_t; st_t = t_; }
+    const int b = blockIdx.x / p.S, sg = blockIdx.x - b * p.S;
+    const int D = p.D;
+    int I = p.t_xs[b], J = p.t_ys[b];
+    I = I > p.Tx ? p.Tx : I;
+    J = J > p.Ty ? p.Ty : J;
+    const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
+    if (!ok) {
+        if (sg == 0 && tid == 0) atomicOr(p.status, ALIGNER_ST_BAD_LENGTHS);
+        return;
+    }
+    const int P = J + 1;
+    int Sb = P / D;
+    Sb = Sb < 1 ? 1 : (Sb > p.S ? p.S : Sb);
+    const int n = (P + Sb - 1) / Sb;
+    const int a = sg * n;
+    if (sg >= Sb || a >= P) return;
+    MbSeg g;
+    g.a = a;
+    g.bnd = (a + n < P) ? a + n : P;
+    g.D = D;
+    g.J = J;
+    g.W = p.nmax + D;
+    g.has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
+    g.sM = reinterpret_cast<int *>(smem);
+    g.sS = reinterpret_cast<float *>(g.sM + 2 * g.W);
+    g.sV = g.sS + 2 * g.W;
+    const int bnd = g.bnd, W = g.W;
+    for (int h = tid; h < D; h += T) {             // positions before the utterance's start (segment 0 keeps these)
+        g.sM[h] = MB_DEADM;  g.sM[W + h] = MB_DEADM;
+        g.sS[h] = 0.f;       g.sS[W + h] = 0.f;
+        g.sV[h] = MB_NEG;    g.sV[W + h] = MB_NEG;
+    }
+    const int j1 = a + tid;
+    const bool mine = j1 < bnd;
+    float la = (j1 == 0) ? 0.f : MB_NEG, de = la;  // P(b_-1 = 0) = 1
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    unsigned short *backb = p.back + (size_t)b * p.Tx * p.bstride;
+    unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;          // this lane's own word (x4: see the plan)
+    g.ring_out = p.ring + ((size_t)b * (p.S - 1) + (g.has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
+    const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
+    const bool polls = sg > 0 && tid < D;
+    const bool publishes = g.has_next && mine && j1 >= bnd - D;
+
+    // rows [i0, i1]: the segment has a reachable position (an interval: both limits of a row move up with i)
+    int i0 = I, i1 = -1;
+    for (int i = 0; i < I; ++i) {
+        int lo, hi;
+        mb_bounds(I, J, D, i, lo, hi);
+        const long long reach = (long long)(i + 1) * D;
+        const int hi2 = hi < reach ? hi : (int)reach;
+        if (lo < bnd && hi2 >= a && lo <= hi2) {
+            i0 = i0 > i ? i : i0;
+            i1 = i;
+        }
+    }
+    auto dead_rows = [&](int from, int to) {      // rows without a reachable position: "log 0" everywhere
+        for (int i = from; i < to; ++i) {
+            if (g.has_next)
+                for (int h = tid; h < D; h += T) {
+                    unsigned *r = g.ring_out + (size_t)i * 3 * D + h;
+                    mb_ring_store(r, __builtin_bit_cast(unsigned, (float)MB_DEADM));
+                    mb_ring_store(r + D, 0u);
+                    mb_ring_store(r + 2 * D, __builtin_bit_cast(unsigned, MB_NEG));
+                }
+            if (WANT_LA && mine && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+        }
+    };
+    if (i1 < 0) {                                  // never reachable (an utterance much shorter than the batch's Ty)
+        dead_rows(0, I);
+        if (mine && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+        return;
+    }
+    dead_rows(0, i0);
+
+    // operands of a row, all lanes, clamped addresses
+    const int je = (j1 < 1 ? 1 : (j1 > J ? J : j1)) - 1;               // frame of this lane's boundary position
+    const int kl = j1 > J - 1 ? J - 1 : j1;                            // the step out of J does not exist (phase 1)
+    unsigned e_nx, h0_nx, h1_nx, h2_nx;
+    float L_nx;
+    auto issue = [&](int i) {
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        e_nx = mb_load_raw<VT>(p.e, ro + je);
+        L_nx = p.Lw[ro + kl];
+        const unsigned *r = polls ? ring_in + (size_t)i * 3 * D + tid : trash;
+        const int st = polls ? D : 0;
+        h0_nx = mb_ring_load(r);
+        h1_nx = mb_ring_load(r + st);
+        h2_nx = mb_ring_load(r + 2 * st);
+    };
+    bool gave_up = false;
+    if (sg > 0 && p.start_lag > 0) {
+        // Let the segment before get `start_lag` rows ahead first.  A row's halo is fetched a row early (issue());
+        // that only finds it if the producer is more than a row + the visibility latency ahead -- two segments in
+        // step pay a round trip to memory per row (measured: 1 200-3 000 cycles of every row).
+        int ig = i0 + p.start_lag;
+        ig = ig > I - 1 ? I - 1 : ig;
+        const unsigned *r = ring_in + (size_t)ig * 3 * D + (tid < D ? tid : 0) + 2 * D;    // the row's last word
+        int spins = 0;
+        while (mb_ring_load(r) == MB_FILL && !gave_up) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > p.spin_limit) gave_up = true;
+        }
+    }
+    issue(i0);
+    // The loop is entered in the state every later row finds: the row's operand loads followed by four stores
+    // (three ring words, one duration).  hipcc sizes a counted wait for the FEWEST operations that can follow on any
+    // path into it: without these four the halo's wait inside the loop came out as vmcnt(8) instead of vmcnt(12) and
+    // also waited for the previous row's stores to be acknowledged -- 1 200 cycles of every row.
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    if (WANT_LA) mb_ring_store(trash, 0u);
+    unsigned long long st_loop = 0;
+    if (stamping) { st_loop = st_t = __builtin_amdgcn_s_memtime(); }
+#pragma unroll 1
+    for (int i = i0; i <= i1; ++i) {
+        int lo, hi;
+        mb_bounds(I, J, D, i, lo, hi);
+        const unsigned e_c = e_nx, h_c0 = h0_nx, h_c1 = h1_nx, h_c2 = h2_nx;
+        const float L_c = L_nx;
+        issue(i + 1 < I ? i + 1 : I - 1);
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        const int bo = (i & 1) * W;
+        if (stamping) { asm volatile("" :: "v"(e_c), "v"(L_c), "v"(h_c0)); }
+        MB_STAMP(0)
+        // ---- phase 1 ----
+        {
+            const float L = (j1 < J) ? L_c : MB_NEG;
+            const bool live = L > MB_DEADF;
+            const float u = (live && la > MB_DEADF) ? la - L : MB_NEG;
+            float v = (live && de > MB_DEADF) ? de - L : MB_NEG;
+            v = (v > MB_DEADF) ? v : MB_NEG;
+            int M;
+            float s;
+            mb_encode(u, M, s);
+            if (mine) {
+                const int x = bo + D + tid;
+                g.sM[x] = M;
+                g.sS[x] = s;
+                g.sV[x] = v;
+            }
+            unsigned *r = publishes ? g.ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
+            const int st = publishes ? D : 0;
+            mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
+            mb_ring_store(r + st, __builtin_bit_cast(unsigned, s));
+            mb_ring_store(r + 2 * st, __builtin_bit_cast(unsigned, v));
+        }
+        MB_STAMP(1)
+        if (sg > 0) {
+            // this lane's own halo entry comes from the words fetched a row ago: its test must not share a join with a
+            // path that loads (hipcc would then wait vmcnt(0) here -- for the operand loads issued a moment ago)
+            auto halo_entry = [&](int h, unsigned w0, unsigned w1, unsigned w2) {
+                if (w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL) {          // not published yet: poll
+                    const unsigned *r = ring_in + (size_t)i * 3 * D + h;
+                    int spins = 0;
+                    do {
+                        __builtin_amdgcn_s_sleep(2);
+                        w0 = mb_ring_load(r);
+                        w1 = mb_ring_load(r + D);
+                        w2 = mb_ring_load(r + 2 * D);
+                        if (++spins > p.spin_limit) gave_up = true;
+                    } while ((w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL) && !gave_up);
+                    if (stamping) st_polls += (unsigned long long)spins;
+                }
+                const bool bad = (w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL);
+                g.sM[bo + h] = bad ? MB_DEADM : (int)__builtin_bit_cast(float, w0);
+                g.sS[bo + h] = bad ? 0.f : __builtin_bit_cast(float, w1);
+                g.sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, w2);
+            };
+            if (tid < D) halo_entry(tid, h_c0, h_c1, h_c2);
+            if (D > T) {
+#pragma unroll 1
+                for (int h = tid + T; h < D; h += T) halo_entry(h, MB_FILL, MB_FILL, MB_FILL);
+            }
+        }
+        MB_STAMP(2)
+        mb_lds_barrier();
+        MB_STAMP(3)
+        // ---- phase 2 ----
+        {
+            const float ev = mb_value<VT>(e_c) * MB_LOG2E;
+            float lav, dev;
+            int dur;
+            mb_phase2(g, bo, mine ? j1 : a, mine ? lo : 1, mine ? hi : 0, ev, lav, dev, dur);
+            la = lav;
+            de = dev;
+            if (stamping) { asm volatile("" :: "v"(la), "v"(de)); }
+            MB_STAMP(4)
+            unsigned short *bp = mine ? backb + (size_t)i * p.bstride + j1 : reinterpret_cast<unsigned short *>(trash);
+            *bp = (unsigned short)dur;
+            if (WANT_LA) {
+                float *lp = (mine && j1 >= 1) ? p.log_alpha + ro + (j1 - 1) : reinterpret_cast<float *>(trash);
+                *lp = (lav > MB_DEADF) ? lav * MB_LN2 : -__builtin_huge_valf();
+            }
+        }
+        MB_STAMP(5)
+    }
+    if (stamping) {
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 16;
+        o[0] = st_entry; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime();
+        for (int q = 0; q < 6; ++q) o[3 + q] = st_acc[q];
+        o[9] = (unsigned long long)(i1 - i0 + 1); o[10] = (unsigned long long)i0; o[11] = st_rt; o[12] = __builtin_amdgcn_s_memrealtime(); o[13] = st_polls;
+    }
+#undef MB_STAMP
+    if (mine && j1 == J && i1 == I - 1 && p.map_score)
+        p.map_score[b] = (de > MB_DEADF) ? de * MB_LN2 : -__builtin_huge_valf();
+    if (i1 + 1 < I) {
+        // row i1+1: nothing reachable here any more, but the states of row i1 are still owed to the next segment
+        const int i = i1 + 1;
+        if (publishes) {
+            const float Lr = p.Lw[ubase + (size_t)i * p.Ty + kl];
+            const float L = (j1 < J) ? Lr : MB_NEG;
+            const bool live = L > MB_DEADF;
+            const float u = (live && la > MB_DEADF) ? la - L : MB_NEG;
+            float v = (live && de > MB_DEADF) ? de - L : MB_NEG;
+            v = (v > MB_DEADF) ? v : MB_NEG;
+            int M;
+            float s;
+            mb_encode(u, M, s);
+            unsigned *r = g.ring_out + (size_t)i * 3 * D + (j1 - (bnd - D));
+            mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
+            mb_ring_store(r + D, __builtin_bit_cast(unsigned, s));
+            mb_ring_store(r + 2 * D, __builtin_bit_cast(unsigned, v));
+        }
+        if (WANT_LA && mine && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+        dead_rows(i1 + 2, I);
+        if (mine && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+    }
+    if (gave_up) {
+        atomicOr(p.status, ALIGNER_ST_INTERNAL);
+        p.failw[b] = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 3. Backtrack of the MAP sequence: RB rows at a time.  After t steps from position j the walk is within
 //    [j - t*D, j - t], so the durations of the batch's rows over those windows are fetched in one go.
@@ -457,7 +714,8 @@ __global__ __launch_bounds__(256) void mobo_backtrack_kernel(MoboParams p, int R
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_j, s_bad;
     __shared__ int s_b[64], s_d[64];
-    unsigned short *win = reinterpret_cast<unsigned short *>(smem);
+    typedef unsigned piece_t __attribute__((ext_vector_type(4)));      // 8 durations
+    piece_t *win = reinterpret_cast<piece_t *>(smem);
     const int tid = threadIdx.x, b = blockIdx.x, D = p.D;
     int I = p.t_xs[b], J = p.t_ys[b];
     I = I > p.Tx ? p.Tx : I;
@@ -477,23 +735,42 @@ __global__ __launch_bounds__(256) void mobo_backtrack_kernel(MoboParams p, int R
         bo[i] = J;
         if (du) du[i] = 0;
     }
-    const unsigned short *backb = p.back + (size_t)b * p.Tx * (p.Ty + 1);
-    const int ws = (RB - 1) * D + 1;               // entries kept per row of a batch
+    const unsigned short *backb = p.back + (size_t)b * p.Tx * p.bstride;
+    // Row t of a batch (token i-t) is needed over positions [j - t*D, j - t]; it is fetched in aligned pieces of 8
+    // entries, 256/RB threads per row and at most 16 pieces per thread, ALL in flight before the first is used.
+    const int tpr = 256 / RB, t_of = tid / tpr, c_of = tid - t_of * tpr;
+    const int wp = ((RB - 1) * D + 8) / 8 + 1;      // pieces kept per row
     if (tid == 0) { s_j = J; s_bad = 0; }
     __syncthreads();
     for (int i = I - 1; i >= 0; i -= RB) {
         const int nb = (i + 1 < RB) ? i + 1 : RB;
         const int j = s_j;
-        for (int t = 0; t < nb; ++t) {              // row i-t: positions j - t*D .. j - t
-            const int base = j - t * D, cnt = t * (D - 1) + 1;
-            const unsigned short *src = backb + (size_t)(i - t) * (p.Ty + 1);
-            for (int c = tid; c < cnt; c += 256) win[t * ws + c] = (base + c >= 0) ? src[base + c] : (unsigned short)0;
+        {
+            const int t = t_of;
+            int first = j - t * D;                                    // first position of the row's window ...
+            first = first < 0 ? 0 : first;
+            const int p0 = first >> 3, p1 = (j - t) >> 3;             // ... and its pieces p0 .. p1 (none if j < t)
+            const piece_t *src = reinterpret_cast<const piece_t *>(backb + (size_t)(i - t) * p.bstride);
+            piece_t r[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pc = p0 + c_of + q * tpr;
+                r[q] = (t < nb && j >= t && pc <= p1) ? __builtin_nontemporal_load(src + pc) : piece_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int pc = c_of + q * tpr;
+                if (pc < wp) win[t * wp + pc] = r[q];
+            }
         }
         __syncthreads();
         if (tid == 0) {
+            const unsigned short *w16 = reinterpret_cast<const unsigned short *>(win);
             int jj = j;
             for (int t = 0; t < nb; ++t) {
-                const int d = win[t * ws + (jj - (j - t * D))];
+                int first = j - t * D;
+                first = first < 0 ? 0 : first;
+                const int d = w16[(size_t)t * wp * 8 + (jj - (first & ~7))];
                 s_b[t] = jj;
                 s_d[t] = d;
                 if (d < 1 || d > D || d > jj) { s_bad = 1; jj = 0; break; }
@@ -559,9 +836,9 @@ __global__ __launch_bounds__(256) void mobo_gamma_kernel(const float *__restrict
 // launch plan: D, segments per utterance, positions per segment, threads, workspace layout
 // ---------------------------------------------------------------------------------------------------------
 struct MoboPlan {
-    int D, S, nmax, NP, T, RB;
+    int D, S, nmax, NP, T, RB, bstride;
     size_t lds, bt_lds, ring_words;
-    size_t status_off, fail_off, L_off, back_off, ring_off, total;
+    size_t status_off, fail_off, trash_off, L_off, back_off, ring_off, total;
 };
 
 static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool quiet) {
@@ -593,15 +870,18 @@ static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool
     pl.NP = nmax <= 1024 ? 1 : 2;                  // 1: a position per thread (registers); 2: "several" (LDS, loops)
     pl.T = nmax <= 1024 ? (nmax + 63) / 64 * 64 : 1024;
     pl.lds = lds;
-    int RB = (int)std::sqrt(32768.0 / D);
-    pl.RB = RB < 1 ? 1 : (RB > 32 ? 32 : RB);
-    pl.bt_lds = (size_t)pl.RB * ((size_t)(pl.RB - 1) * D + 1) * sizeof(unsigned short);
+    int RB = 32;                                   // rows per backtrack batch: a power of two with RB^2 * D <= 32768
+    while (RB > 1 && (long long)RB * RB * D > 32768) RB >>= 1;
+    pl.RB = RB;
+    pl.bt_lds = (size_t)RB * (((size_t)(RB - 1) * D + 8) / 8 + 1) * 16;
     pl.ring_words = (size_t)B * (S - 1) * Tx * 3 * D;
     pl.status_off = 0;
     pl.fail_off = 256;
-    pl.L_off = align_up(pl.fail_off + (size_t)B * sizeof(int), 256);
+    pl.trash_off = align_up(pl.fail_off + (size_t)B * sizeof(int), 256);
+    pl.L_off = align_up(pl.trash_off + ((size_t)B * S * 1024 + 64) * sizeof(unsigned), 256);
     pl.back_off = align_up(pl.L_off + (size_t)B * Tx * Ty * sizeof(float), 256);
-    pl.ring_off = align_up(pl.back_off + (size_t)B * Tx * (Ty + 1) * sizeof(unsigned short), 256);
+    pl.bstride = (Ty + 1 + 7) / 8 * 8;
+    pl.ring_off = align_up(pl.back_off + (size_t)B * Tx * pl.bstride * sizeof(unsigned short), 256);
     pl.total = align_up(pl.ring_off + pl.ring_words * sizeof(unsigned), 256);
     return ALIGNER_OK;
 }
@@ -623,7 +903,8 @@ size_t aligner_boundary_search_workspace_bytes(int B, int Tx, int Ty) {
     if (B < 0 || Tx < 1 || Ty < 1) return 0;
     // whatever the window: the ring holds (S-1)*D <= Ty positions of 3 words per token row
     const size_t fixed = 256 + align_up((size_t)B * sizeof(int), 256) + align_up((size_t)B * Tx * Ty * sizeof(float), 256) +
-                         align_up((size_t)B * Tx * (Ty + 1) * sizeof(unsigned short), 256);
+                         align_up(((size_t)(B > 1024 ? B : 1024 + B) * 1024 + 64) * sizeof(unsigned), 256) +
+                         align_up((size_t)B * Tx * ((size_t)Ty + 8) * sizeof(unsigned short), 256);
     return fixed + align_up((size_t)B * Tx * 3 * ((size_t)Ty + 1) * sizeof(unsigned), 256) + 256;
 }
 
@@ -650,7 +931,8 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
     MoboParams p{energies, t_xs, t_ys, log_alpha_out, boundaries_out, durations_out, map_score_out,
                  reinterpret_cast<float *>(ws + pl.L_off), reinterpret_cast<unsigned short *>(ws + pl.back_off),
                  reinterpret_cast<unsigned *>(ws + pl.ring_off), reinterpret_cast<int *>(ws + pl.fail_off),
-                 reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, pl.D, pl.S, pl.nmax,
+                 reinterpret_cast<unsigned *>(ws + pl.trash_off),
+                 reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, pl.D, pl.S, pl.nmax, pl.bstride, g_opt_mobo_start_lag, g_debug_stamps,
                  g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
     {   // 1. normalisers (+ ring refill)
         const size_t nlds = (size_t)(256 + pl.D) * 8;
@@ -673,7 +955,9 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
             return ALIGNER_OK;
         };
         int rc;
-#define MB_LAUNCH_NP(VT_) (pl.NP == 1 ? launch(mobo_chain_kernel<VT_, false>) : launch(mobo_chain_kernel<VT_, true>))
+#define MB_LAUNCH_NP(VT_)                                                                               \
+    (pl.NP != 1 ? launch(mobo_chain_kernel<VT_, true>)                                                  \
+     : log_alpha_out ? launch(mobo_chain_one_kernel<VT_, true>) : launch(mobo_chain_one_kernel<VT_, false>))
         rc = vt == 0 ? MB_LAUNCH_NP(0) : vt == 1 ? MB_LAUNCH_NP(1) : MB_LAUNCH_NP(2);
         if (rc) return rc;
     }
