@@ -44,7 +44,8 @@ int device_cu_count();                // compute units of the current device (ca
 // development aid shared by the kernel files (aligner_debug_set_stamps)
 extern unsigned long long *g_debug_stamps;
 extern int g_opt_softattn_exact;       // "softattn_exact": always the exact-product similarity kernel
-extern int g_opt_mobo_start_lag;       // "mobo_start_lag": rows a position segment lets its predecessor get ahead (default 2)
+extern int g_opt_mobo_start_lag;       // "mobo_start_lag": rows a position segment lets its predecessor get ahead (default 1)
+extern int g_opt_mobo_lanes;           // "mobo_lanes": development, lanes per position in the split form (0: the plan's choice)
 extern int g_opt_mobo_drop_segment;    // "mobo_drop_segment": testing, that position segment never publishes (-1: off)
 extern int g_opt_fwdsum_one_wave;      // aligner_debug_set_option("fwdsum_one_wave", ...); default: env, read once
 

@@ -453,22 +453,95 @@ __global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
     }
 }
 
-// The split form: one position per thread, everything a row needs in flight a row ahead.
+// ---- cross-lane helpers of the split form -------------------------------------------------------------------
+__device__ __forceinline__ int mb_quad_xor_i(int v, int m) {       // the value of lane (lane ^ m), m = 1 or 2
+    return m == 1 ? __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float mb_quad_xor_f(float v, int m) {
+    return __builtin_bit_cast(float, mb_quad_xor_i(__builtin_bit_cast(int, v), m));
+}
+__device__ __forceinline__ int mb_wave_max_i32(int v) {            // maximum over the wave's 64 lanes (uniform result)
+#define MB_DPP_MAX(ctrl_, rows_)                                                          \
+    {                                                                                     \
+        const int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl_, rows_, 0xF, false);       \
+        v = v > o_ ? v : o_;                                                              \
+    }
+    MB_DPP_MAX(0x111, 0xF)      // row_shr:1
+    MB_DPP_MAX(0x112, 0xF)      // row_shr:2
+    MB_DPP_MAX(0x114, 0xF)      // row_shr:4
+    MB_DPP_MAX(0x118, 0xF)      // row_shr:8   -> lane 15 of every row holds its row's maximum
+    MB_DPP_MAX(0x142, 0xA)      // row_bcast:15 into rows 1 and 3
+    MB_DPP_MAX(0x143, 0xC)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+#undef MB_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One part of a window for the FAST sum: plain fp32 terms t = 2^(u - R) against the row's common reference R (see
+// the kernel), and the same maximum search as mb_window.  (Groups of 16 with the position of the maximum found in
+// registers measured slower: 1 300 against 1 010 cycles per row.)
+__device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, const float *__restrict__ sV, int cnt,
+                                               float &acc, float &best, int &qbest) {
+    acc = 0.f;
+    best = MB_NEG;
+    qbest = 0;
+    int c = 0;
+    const int r = cnt & 7;
+    for (; c < r; ++c) {
+        acc += sT[c];
+        const float v = sV[c];
+        if (v >= best) {
+            best = v;
+            qbest = c;
+        }
+    }
+    int cbest = -1;
+    for (; c < cnt; c += 8) {
+        float t[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            t[u] = sT[c + u];
+            v[u] = sV[c + u];
+        }
+        acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        float vm = v[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) vm = __builtin_fmaxf(vm, v[u]);
+        if (vm >= best) {
+            best = vm;
+            cbest = c;
+        }
+    }
+    if (cbest >= 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (sV[cbest + u] == best) qbest = cbest + u;
+    }
+}
+
+// The split form: one position per H lanes, everything a row needs in flight a row ahead.
 //
-// What paces a row here is not arithmetic but `s_waitcnt`: loads, stores and atomics retire through ONE counter
-// in issue order, and hipcc can only emit a counted wait (leave the N youngest operations in flight) when it can
-// prove N operations follow -- anything behind a branch counts as "maybe" and turns the wait into vmcnt(0), which
-// then also waits for the row's result stores to be acknowledged (measured: 4 500 cycles a row instead of ~1 200).
-// So the rows in which the segment has a reachable position run as one straight-line body: every lane issues every
-// load and store of the row, lanes with nothing to say address a trash area of the workspace, and the first use
-// of the prefetched operands waits behind exactly the stores issued after them.  Rows before / after that range
-// only hand "log 0" entries on.
-template <int VT, bool WANT_LA>
+// What paces a row here is first of all `s_waitcnt`: loads, stores and atomics retire through ONE counter in issue
+// order, and hipcc can only emit a counted wait (leave the N youngest operations in flight) when it can prove N
+// operations follow -- anything behind a branch counts as "maybe" and turns the wait into vmcnt(0), which then also
+// waits for the row's result stores to be acknowledged (measured: 4 500 cycles a row instead of 3 300).  So the rows
+// in which the segment has a reachable position run as one straight-line body: every lane issues every load and
+// store of the row, lanes with nothing to say address a trash area of the workspace, and the first use of the
+// prefetched operands waits behind exactly the stores issued after them.  Rows before / after that range only hand
+// "log 0" entries on.
+//
+// Then the windows.  H lanes share a position's window (H = 1, 2, 4: a split utterance leaves SIMDs idle otherwise)
+// and meet through two DPP quad exchanges.  And a row normally takes the FAST sum: next to the exact (M, s) pair every
+// entry also leaves t = 2^(u - R) as a plain float, R an integer reference common to the whole workgroup (the
+// largest M of the row before); while every live M of the row -- halo included -- lies within 100 of R, all terms
+// and every window's own largest term are normal floats of full precision, and a window is D additions.  Each wave
+// reports whether its entries fit (and their maximum, the next row's R); a row with an entry out of range takes
+// the exact sum, which needs no reference.
+template <int VT, bool WANT_LA, int H, bool STAMPS>
 __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, T = blockDim.x;
-    const bool stamping = p.stamps != nullptr && tid == 0;
-    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_t = 0, st_entry = 0, st_rt = 0, st_polls = 0;
+    const bool stamping = STAMPS && p.stamps != nullptr && tid == 0;      // (a build of its own: the stamps cost registers)
+    unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_entry = 0, st_rt = 0, st_polls = 0, st_slow = 0;
     if (stamping) { st_entry = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
 #define MB_STAMP(k_) if (stamping) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k_] += t_ - st_t; st_t = t_; }
     const int b = blockIdx.x / p.S, sg = blockIdx.x - b * p.S;
@@ -487,32 +560,36 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     const int n = (P + Sb - 1) / Sb;
     const int a = sg * n;
     if (sg >= Sb || a >= P) return;
-    MbSeg g;
-    g.a = a;
-    g.bnd = (a + n < P) ? a + n : P;
-    g.D = D;
-    g.J = J;
-    g.W = p.nmax + D;
-    g.has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
-    g.sM = reinterpret_cast<int *>(smem);
-    g.sS = reinterpret_cast<float *>(g.sM + 2 * g.W);
-    g.sV = g.sS + 2 * g.W;
-    const int bnd = g.bnd, W = g.W;
+    const int bnd = (a + n < P) ? a + n : P;
+    const bool has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
+    const int W = p.nmax + D;                      // entries per buffer
+    int *sM = reinterpret_cast<int *>(smem);
+    float *sS = reinterpret_cast<float *>(sM + 2 * W);
+    float *sV = sS + 2 * W;
+    float *sT = sV + 2 * W;
+    int *sStat = reinterpret_cast<int *>(sT + 2 * W);   // [3 rows in rotation][2]: largest live M, "an entry does not fit"
+    if (tid < 6) sStat[tid] = (tid & 1) ? 0 : MB_DEADM;
     for (int h = tid; h < D; h += T) {             // positions before the utterance's start (segment 0 keeps these)
-        g.sM[h] = MB_DEADM;  g.sM[W + h] = MB_DEADM;
-        g.sS[h] = 0.f;       g.sS[W + h] = 0.f;
-        g.sV[h] = MB_NEG;    g.sV[W + h] = MB_NEG;
+        sM[h] = MB_DEADM;  sM[W + h] = MB_DEADM;
+        sS[h] = 0.f;       sS[W + h] = 0.f;
+        sV[h] = MB_NEG;    sV[W + h] = MB_NEG;
+        sT[h] = 0.f;       sT[W + h] = 0.f;
     }
-    const int j1 = a + tid;
+    mb_lds_barrier();                              // (the report slots are updated with atomics by every wave)
+    const int pi = tid / H, sub = tid - pi * H;    // H consecutive lanes per position
+    const int j1 = a + pi;
     const bool mine = j1 < bnd;
+    const bool lead = mine && sub == 0;            // the lane of a position that writes its results
     float la = (j1 == 0) ? 0.f : MB_NEG, de = la;  // P(b_-1 = 0) = 1
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
     unsigned short *backb = p.back + (size_t)b * p.Tx * p.bstride;
-    unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;          // this lane's own word (x4: see the plan)
-    g.ring_out = p.ring + ((size_t)b * (p.S - 1) + (g.has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
+    unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;
+    unsigned *ring_out = p.ring + ((size_t)b * (p.S - 1) + (has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
     const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
     const bool polls = sg > 0 && tid < D;
-    const bool publishes = g.has_next && mine && j1 >= bnd - D;
+    const bool publishes = has_next && lead && j1 >= bnd - D;
+    // this lane's part of a window: entries [w0, w1) of its D
+    const int w0 = (sub * D) / H, w1 = ((sub + 1) * D) / H;
 
     // rows [i0, i1]: the segment has a reachable position (an interval: both limits of a row move up with i)
     int i0 = I, i1 = -1;
@@ -528,19 +605,19 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     }
     auto dead_rows = [&](int from, int to) {      // rows without a reachable position: "log 0" everywhere
         for (int i = from; i < to; ++i) {
-            if (g.has_next)
+            if (has_next)
                 for (int h = tid; h < D; h += T) {
-                    unsigned *r = g.ring_out + (size_t)i * 3 * D + h;
+                    unsigned *r = ring_out + (size_t)i * 3 * D + h;
                     mb_ring_store(r, __builtin_bit_cast(unsigned, (float)MB_DEADM));
                     mb_ring_store(r + D, 0u);
                     mb_ring_store(r + 2 * D, __builtin_bit_cast(unsigned, MB_NEG));
                 }
-            if (WANT_LA && mine && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+            if (WANT_LA && lead && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
         }
     };
     if (i1 < 0) {                                  // never reachable (an utterance much shorter than the batch's Ty)
         dead_rows(0, I);
-        if (mine && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+        if (lead && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
         return;
     }
     dead_rows(0, i0);
@@ -584,6 +661,8 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
     if (WANT_LA) mb_ring_store(trash, 0u);
+    int R = 0;                                     // the row's reference for the fast sum
+    int slot = 0;                                  // row index mod 3 (the waves' reports)
     unsigned long long st_loop = 0;
     if (stamping) { st_loop = st_t = __builtin_amdgcn_s_memtime(); }
 #pragma unroll 1
@@ -597,7 +676,9 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         const int bo = (i & 1) * W;
         if (stamping) { asm volatile("" :: "v"(e_c), "v"(L_c), "v"(h_c0)); }
         MB_STAMP(0)
-        // ---- phase 1 ----
+        // ---- phase 1: u = la_{i-1}(k) - L_i(k), v = delta_{i-1}(k) - L_i(k) ----
+        int Mstat = MB_DEADM;                      // largest live M this lane has seen in the row
+        bool fits = true;
         {
             const float L = (j1 < J) ? L_c : MB_NEG;
             const bool live = L > MB_DEADF;
@@ -607,13 +688,18 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
             int M;
             float s;
             mb_encode(u, M, s);
-            if (mine) {
-                const int x = bo + D + tid;
-                g.sM[x] = M;
-                g.sS[x] = s;
-                g.sV[x] = v;
+            if (lead) {
+                const int x = bo + D + pi;
+                sM[x] = M;
+                sS[x] = s;
+                sV[x] = v;
+                sT[x] = __builtin_ldexpf(s, M - R);
+                if (M != MB_DEADM) {
+                    Mstat = M;
+                    fits = M >= R - 100 && M <= R + 100;
+                }
             }
-            unsigned *r = publishes ? g.ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
+            unsigned *r = publishes ? ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
             const int st = publishes ? D : 0;
             mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
             mb_ring_store(r + st, __builtin_bit_cast(unsigned, s));
@@ -623,23 +709,30 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         if (sg > 0) {
             // this lane's own halo entry comes from the words fetched a row ago: its test must not share a join with a
             // path that loads (hipcc would then wait vmcnt(0) here -- for the operand loads issued a moment ago)
-            auto halo_entry = [&](int h, unsigned w0, unsigned w1, unsigned w2) {
-                if (w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL) {          // not published yet: poll
+            auto halo_entry = [&](int h, unsigned x0, unsigned x1, unsigned x2) {
+                if (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) {          // not published yet: poll
                     const unsigned *r = ring_in + (size_t)i * 3 * D + h;
                     int spins = 0;
                     do {
                         __builtin_amdgcn_s_sleep(2);
-                        w0 = mb_ring_load(r);
-                        w1 = mb_ring_load(r + D);
-                        w2 = mb_ring_load(r + 2 * D);
+                        x0 = mb_ring_load(r);
+                        x1 = mb_ring_load(r + D);
+                        x2 = mb_ring_load(r + 2 * D);
                         if (++spins > p.spin_limit) gave_up = true;
-                    } while ((w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL) && !gave_up);
+                    } while ((x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) && !gave_up);
                     if (stamping) st_polls += (unsigned long long)spins;
                 }
-                const bool bad = (w0 == MB_FILL || w1 == MB_FILL || w2 == MB_FILL);
-                g.sM[bo + h] = bad ? MB_DEADM : (int)__builtin_bit_cast(float, w0);
-                g.sS[bo + h] = bad ? 0.f : __builtin_bit_cast(float, w1);
-                g.sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, w2);
+                const bool bad = (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL);
+                const int M = bad ? MB_DEADM : (int)__builtin_bit_cast(float, x0);
+                const float sv = bad ? 0.f : __builtin_bit_cast(float, x1);
+                sM[bo + h] = M;
+                sS[bo + h] = sv;
+                sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, x2);
+                sT[bo + h] = __builtin_ldexpf(sv, M - R);
+                if (M != MB_DEADM) {
+                    Mstat = Mstat > M ? Mstat : M;
+                    fits = fits && M >= R - 100 && M <= R + 100;
+                }
             };
             if (tid < D) halo_entry(tid, h_c0, h_c1, h_c2);
             if (D > T) {
@@ -647,36 +740,103 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 for (int h = tid + T; h < D; h += T) halo_entry(h, MB_FILL, MB_FILL, MB_FILL);
             }
         }
+        MB_STAMP(6)
+        {   // what this wave reports about the row: one LDS atomic each into the row's slot (three slots in rotation)
+            const int wm = mb_wave_max_i32(Mstat);
+            const bool wfit = __builtin_amdgcn_ballot_w64(!fits) == 0;
+            if ((tid & 63) == 0) {
+                atomicMax(&sStat[2 * slot], wm);
+                if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
+            }
+        }
         MB_STAMP(2)
         mb_lds_barrier();
         MB_STAMP(3)
-        // ---- phase 2 ----
+        // ---- phase 2: the windows [j-D, j) ----
         {
+            const int Rn = sStat[2 * slot], slow = sStat[2 * slot + 1];
+            {   // the slot of the row after next: every wave has read it (row i-1) before this row's barrier
+                const int nslot = slot == 0 ? 2 : slot - 1;         // (i + 2) % 3 when slot = i % 3
+                if (tid == 0) { sStat[2 * nslot] = MB_DEADM; sStat[2 * nslot + 1] = 0; }
+            }
+            if (stamping) { asm volatile("" :: "s"(Rn), "s"(slow)); }
+            MB_STAMP(7)
             const float ev = mb_value<VT>(e_c) * MB_LOG2E;
-            float lav, dev;
-            int dur;
-            mb_phase2(g, bo, mine ? j1 : a, mine ? lo : 1, mine ? hi : 0, ev, lav, dev, dur);
+            const bool feasible = mine && j1 >= lo && j1 <= hi;
+            const int x = bo + (mine ? pi : 0) + w0;           // first entry of this lane's part
+            float lsum = MB_NEG, best;
+            int qb;
+            if (!slow) {
+                float acc;
+                mb_window_fast(sT + x, sV + x, w1 - w0, acc, best, qb);
+#pragma unroll
+                for (int m = 1; m < H; m <<= 1) acc += mb_quad_xor_f(acc, m);
+                if (acc > 0.f) lsum = (float)R + __builtin_amdgcn_logf(acc);
+            } else {
+                if (stamping) ++st_slow;
+                int Mw;
+                float acc;
+                mb_window<true>(sM + x, sS + x, sV + x, w1 - w0, Mw, acc, best, qb);
+#pragma unroll
+                for (int m = 1; m < H; m <<= 1) {
+                    const int Mo = mb_quad_xor_i(Mw, m);
+                    const float ao = mb_quad_xor_f(acc, m);
+                    const int Mn = Mw > Mo ? Mw : Mo;
+                    acc = __builtin_ldexpf(acc, Mw - Mn) + __builtin_ldexpf(ao, Mo - Mn);
+                    Mw = Mn;
+                }
+                if (acc > 0.f) lsum = (float)Mw + __builtin_amdgcn_logf(acc);
+            }
+            if (stamping) { asm volatile("" :: "v"(lsum), "v"(best), "v"(qb)); }
+            MB_STAMP(8)
+            qb += w0;
+#pragma unroll
+            for (int m = 1; m < H; m <<= 1) {                  // the largest v; among equals the largest index
+                const float bo_ = mb_quad_xor_f(best, m);
+                const int qo = mb_quad_xor_i(qb, m);
+                const bool take = bo_ > best || (bo_ == best && qo > qb);
+                best = take ? bo_ : best;
+                qb = take ? qo : qb;
+            }
+            float lav = MB_NEG, dev = MB_NEG;
+            int dur = 0;
+            if (feasible && ev > MB_DEADF) {
+                if (lsum > MB_DEADF) lav = ev + lsum;
+                if (best > MB_DEADF) { dev = ev + best; dur = D - qb; }
+                lav = (lav > MB_DEADF) ? lav : MB_NEG;
+                dev = (dev > MB_DEADF) ? dev : MB_NEG;
+                if (!(dev > MB_DEADF)) dur = 0;
+            }
             la = lav;
             de = dev;
+            R = (Rn != MB_DEADM) ? Rn : R;
             if (stamping) { asm volatile("" :: "v"(la), "v"(de)); }
             MB_STAMP(4)
-            unsigned short *bp = mine ? backb + (size_t)i * p.bstride + j1 : reinterpret_cast<unsigned short *>(trash);
+            unsigned short *bp = lead ? backb + (size_t)i * p.bstride + j1 : reinterpret_cast<unsigned short *>(trash);
             *bp = (unsigned short)dur;
             if (WANT_LA) {
-                float *lp = (mine && j1 >= 1) ? p.log_alpha + ro + (j1 - 1) : reinterpret_cast<float *>(trash);
+                float *lp = (lead && j1 >= 1) ? p.log_alpha + ro + (j1 - 1) : reinterpret_cast<float *>(trash);
                 *lp = (lav > MB_DEADF) ? lav * MB_LN2 : -__builtin_huge_valf();
             }
         }
         MB_STAMP(5)
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    if (STAMPS && p.stamps != nullptr && (tid & 63) == 0 && (tid >> 6) < 6) {      // where each wave ran: HW_ID (+ XCC_ID)
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+        p.stamps[(size_t)blockIdx.x * 24 + 18 + (tid >> 6)] = ((unsigned long long)xcc << 32) | hw;
     }
     if (stamping) {
-        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 16;
+        unsigned long long *o = p.stamps + (size_t)blockIdx.x * 24;
         o[0] = st_entry; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime();
         for (int q = 0; q < 6; ++q) o[3 + q] = st_acc[q];
-        o[9] = (unsigned long long)(i1 - i0 + 1); o[10] = (unsigned long long)i0; o[11] = st_rt; o[12] = __builtin_amdgcn_s_memrealtime(); o[13] = st_polls;
+        o[9] = (unsigned long long)(i1 - i0 + 1); o[10] = (unsigned long long)i0; o[11] = st_rt;
+        o[12] = __builtin_amdgcn_s_memrealtime(); o[13] = st_polls; o[14] = st_slow;
+        o[15] = st_acc[6]; o[16] = st_acc[7]; o[17] = st_acc[8];
     }
 #undef MB_STAMP
-    if (mine && j1 == J && i1 == I - 1 && p.map_score)
+    if (lead && j1 == J && i1 == I - 1 && p.map_score)
         p.map_score[b] = (de > MB_DEADF) ? de * MB_LN2 : -__builtin_huge_valf();
     if (i1 + 1 < I) {
         // row i1+1: nothing reachable here any more, but the states of row i1 are still owed to the next segment
@@ -691,14 +851,14 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
             int M;
             float s;
             mb_encode(u, M, s);
-            unsigned *r = g.ring_out + (size_t)i * 3 * D + (j1 - (bnd - D));
+            unsigned *r = ring_out + (size_t)i * 3 * D + (j1 - (bnd - D));
             mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
             mb_ring_store(r + D, __builtin_bit_cast(unsigned, s));
             mb_ring_store(r + 2 * D, __builtin_bit_cast(unsigned, v));
         }
-        if (WANT_LA && mine && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+        if (WANT_LA && lead && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
         dead_rows(i1 + 2, I);
-        if (mine && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+        if (lead && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
     }
     if (gave_up) {
         atomicOr(p.status, ALIGNER_ST_INTERNAL);
@@ -836,7 +996,7 @@ __global__ __launch_bounds__(256) void mobo_gamma_kernel(const float *__restrict
 // launch plan: D, segments per utterance, positions per segment, threads, workspace layout
 // ---------------------------------------------------------------------------------------------------------
 struct MoboPlan {
-    int D, S, nmax, NP, T, RB, bstride;
+    int D, S, nmax, NP, T, RB, bstride, H;
     size_t lds, bt_lds, ring_words;
     size_t status_off, fail_off, trash_off, L_off, back_off, ring_off, total;
 };
@@ -857,7 +1017,8 @@ static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool
     for (;; ++S) {
         const int n1 = (P + S - 1) / S, n2 = (2 * D < P) ? 2 * D : P;
         nmax = n1 > n2 ? n1 : n2;
-        lds = (size_t)2 * 3 * 4 * ((size_t)nmax + D) + (nmax > 1024 ? (size_t)8 * nmax : 0);
+        lds = nmax > 1024 ? (size_t)2 * 3 * 4 * ((size_t)nmax + D) + (size_t)8 * nmax      // several positions per thread
+                          : (size_t)2 * 4 * 4 * ((size_t)nmax + D) + 64 * sizeof(int);       // the split form (+ fast terms, wave reports)
         if (lds <= (size_t)lds_limit) break;
         if (S >= smax)
             return quiet ? ALIGNER_EDOM
@@ -868,7 +1029,11 @@ static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool
     pl.S = S;
     pl.nmax = nmax;
     pl.NP = nmax <= 1024 ? 1 : 2;                  // 1: a position per thread (registers); 2: "several" (LDS, loops)
-    pl.T = nmax <= 1024 ? (nmax + 63) / 64 * 64 : 1024;
+    // the split form: H lanes per position while that leaves at most one wave per SIMD of a CU
+    pl.H = nmax <= 64 ? 4 : nmax <= 128 ? 2 : 1;
+    if (g_opt_mobo_lanes == 1 || g_opt_mobo_lanes == 2 || g_opt_mobo_lanes == 4)       // development: force it
+        if ((long long)nmax * g_opt_mobo_lanes <= 1024) pl.H = g_opt_mobo_lanes;
+    pl.T = nmax <= 1024 ? (nmax * pl.H + 63) / 64 * 64 : 1024;
     pl.lds = lds;
     int RB = 32;                                   // rows per backtrack batch: a power of two with RB^2 * D <= 32768
     while (RB > 1 && (long long)RB * RB * D > 32768) RB >>= 1;
@@ -957,7 +1122,12 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
         int rc;
 #define MB_LAUNCH_NP(VT_)                                                                               \
     (pl.NP != 1 ? launch(mobo_chain_kernel<VT_, true>)                                                  \
-     : log_alpha_out ? launch(mobo_chain_one_kernel<VT_, true>) : launch(mobo_chain_one_kernel<VT_, false>))
+     : log_alpha_out ? MB_LAUNCH_H(VT_, true) : MB_LAUNCH_H(VT_, false))
+#define MB_LAUNCH_H(VT_, LA_)                                                                            \
+    (g_debug_stamps ? MB_LAUNCH_ST(VT_, LA_, true) : MB_LAUNCH_ST(VT_, LA_, false))
+#define MB_LAUNCH_ST(VT_, LA_, ST_)                                                                      \
+    (pl.H == 1 ? launch(mobo_chain_one_kernel<VT_, LA_, 1, ST_>) : pl.H == 2 ? launch(mobo_chain_one_kernel<VT_, LA_, 2, ST_>) \
+                                                                              : launch(mobo_chain_one_kernel<VT_, LA_, 4, ST_>))
         rc = vt == 0 ? MB_LAUNCH_NP(0) : vt == 1 ? MB_LAUNCH_NP(1) : MB_LAUNCH_NP(2);
         if (rc) return rc;
     }

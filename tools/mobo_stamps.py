@@ -14,7 +14,7 @@ tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), 
 if len(sys.argv) > 5: lib.aligner_debug_set_option(b'mobo_start_lag', int(sys.argv[5]))
 for _ in range(3): aligner_amd.boundary_search(lp, tx, ty, D)
 torch.cuda.synchronize()
-st = torch.zeros((4096, 16), dtype=torch.int64, device=dev)
+st = torch.zeros((4096, 24), dtype=torch.int64, device=dev)
 lib.aligner_debug_set_stamps(st.data_ptr())
 aligner_amd.boundary_search(lp, tx, ty, D)
 torch.cuda.synchronize()
@@ -30,5 +30,19 @@ print("seg  entry  loop_start   end   rows first |  per-row cycles: wait-operand
 for sg in list(range(0, S, max(1, S // 8))) + [S - 1]:
     r = s[sg]   # utterance 0
     rows = max(r[9], 1)
-    print(f"{sg:3d} {r[0]-t0:7.0f} {r[1]-t0:9.0f} {r[2]-t0:9.0f} {int(r[9]):5d} {int(r[10]):5d} | " + " ".join(f"{r[3+q]/rows:8.0f}" for q in range(6)) + f"   polls/row {r[13]/rows:.2f}")
+    print(f"{sg:3d} {r[0]-t0:7.0f} {r[1]-t0:9.0f} {r[2]-t0:9.0f} {int(r[9]):5d} {int(r[10]):5d} | " + " ".join(f"{r[3+q]/rows:8.0f}" for q in range(6)) + f"   polls/row {r[13]/rows:.2f} exact-sum rows {int(r[14])} | halo-entry {r[15]/rows:.0f} (rest of halo = wave report) | stats-read {r[16]/rows:.0f} window {r[17]/rows:.0f} (rest of phase2 = combine)")
 print("kernel span (cycles, first entry to last end):", int(s[:nblk, 2].max() - t0), "=", round((s[:nblk, 2].max() - t0) / np.median(clk) / 1e3, 1), "us")
+
+hw = st.cpu().numpy()[:nblk, 18:24]
+def dec(x):
+    x = int(x); h = x & 0xffffffff
+    return f"xcc{(x >> 32) & 15} se{(h >> 13) & 7} sh{(h >> 12) & 1} cu{(h >> 8) & 15} simd{(h >> 4) & 3} w{h & 15}"
+print("placement of the waves of blocks 0..5:")
+for blk in range(6):
+    print(blk, [dec(x) for x in hw[blk] if x != 0])
+cus = {}
+for blk in range(nblk):
+    x = int(hw[blk][0]); h = x & 0xffffffff
+    key = ((x >> 32) & 15, (h >> 13) & 7, (h >> 12) & 1, (h >> 8) & 15)
+    cus[key] = cus.get(key, 0) + 1
+print("distinct CUs used:", len(cus), "max blocks on one CU:", max(cus.values()))

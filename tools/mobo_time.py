@@ -14,5 +14,9 @@ g = torch.Generator().manual_seed(0)
 B, Tx, Ty = 8, 500, 4000
 lp = (torch.randn(B, Tx, Ty, generator=g) * 2).bfloat16().to(dev)
 tx = torch.full((B,), Tx, dtype=torch.int32, device=dev); ty = torch.full((B,), Ty, dtype=torch.int32, device=dev)
+from aligner_amd import _lib
+lib = _lib.load()
+for k, v in [a.split('=') for a in sys.argv[1:]]:
+    lib.aligner_debug_set_option(k.encode(), int(v))
 for D in (16, 32, 64):
     print("D=%d: %.1f us" % (D, ev(lambda: aligner_amd.boundary_search(lp, tx, ty, D))))
