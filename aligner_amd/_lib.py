@@ -25,6 +25,7 @@ F_WRITE_Q = 64
 F_STREAM_PATH = 128
 F_ONE_CU = 256
 F_TWO_CUS = 512
+F_TEST_DROP_FIRST_HALF = 1024
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2
@@ -122,13 +123,20 @@ class StreamWorkspaces:
     Every entry point is asynchronous on the caller's current stream and its workspace holds
     live state between the launches of one call (token starts, decision words, status word), so
     two calls in flight on different streams of one device must never share a buffer.  Buffers
-    come from torch's caching allocator while their stream is current, which makes growing one
-    (dropping the old tensor) stream-ordered as well."""
+    come from torch's caching allocator while their stream is current.
+
+    Growing: a larger buffer replaces the old one for later calls; the old one's sticky status word is
+    OR-ed into the new one on the stream (read_status() promises "since the last read"), and the old
+    buffer is kept alive in `retired` until release() -- a HIP graph captured through align() still
+    launches into it.  Entries are keyed by the raw stream handle and live until release(): callers that
+    capture graphs or create streams at a high rate should own their workspaces through the C ABI
+    (bench.py does) or call release(stream) when a stream is done."""
 
     def __init__(self, zero: bool, slack: float = 1.25):
         self.zero = zero
         self.slack = slack
         self.bufs: dict = {}
+        self.retired: dict = {}
 
     def get(self, device, nbytes: int):
         import torch
@@ -137,9 +145,22 @@ class StreamWorkspaces:
         if ws is None or ws.numel() < nbytes:
             n = int(nbytes * self.slack) + 256
             with torch.cuda.device(device):
-                ws = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
-            self.bufs[key] = ws
+                new = (torch.zeros if self.zero else torch.empty)(n, dtype=torch.uint8, device=device)
+                if ws is not None:
+                    if self.zero:                     # carry the sticky status word over (stream-ordered)
+                        new[:4].view(torch.int32).bitwise_or_(ws[:4].view(torch.int32))
+                    self.retired.setdefault(key, []).append(ws)
+            self.bufs[key] = ws = new
         return ws
 
     def on_device(self, device):
         return [ws for (d, _), ws in self.bufs.items() if d == device]
+
+    def release(self, device=None, stream=None) -> None:
+        """Drop the buffers of one stream (or of every stream of `device`, or all).  The caller vouches
+        that no work -- and no captured graph -- still uses them."""
+        for key in list(self.bufs):
+            d, s = key
+            if (device is None or d == device) and (stream is None or s == stream):
+                self.bufs.pop(key, None)
+                self.retired.pop(key, None)

@@ -741,8 +741,11 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 // waves' code is the one-workgroup code: any store of theirs that hipcc could not tell from a load made every tile
 // wait for the previous tile's stores), the second half's first loader wave reads them four tiles ahead and polls until no
 // word is the filler (a running score is finite; a NaN with that bit pattern is rewritten before it is stored) --
-// the data is its own flag, nothing waits for a store to complete.  The first half never waits for the second
-// (lower block indices are dispatched first), so the pair cannot deadlock; the second half waits once more, for
+// the data is its own flag, nothing waits for a store to complete.  The first half never waits for the second, so
+// the pair cannot deadlock once both are resident; that lower block indices are dispatched first is how the
+// hardware behaves, not a HIP guarantee, so the host only takes this form when all 2B workgroups fit the chip at
+// once (2B <= CU count), every wait is bounded, and a second half that gave up leaves an all-zero path, zero durations
+// and ALIGNER_ST_INTERNAL behind -- never a path walked over filler.  The second half waits once more, for
 // the first half's decision words (release / acquire on xflag), and then runs the backtrack for the utterance.
 constexpr unsigned XRING_EMPTY = 0xFFFFFFFFu;
 constexpr int XRING_SPIN_LIMIT = 1 << 18;          // polls before giving up for good with ALIGNER_ST_INTERNAL (~0.3 s)
@@ -764,6 +767,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     // paired: this utterance really has rows for the second workgroup; otherwise the first one does everything
     const bool paired = PAIR && (tx + RPW - 1) / RPW > NW;
     if (PAIR && half == 1 && !paired) return;
+    if (PAIR && paired && half == 0 && (p.flags & ALIGNER_F_TEST_DROP_FIRST_HALF)) return;   // testing: never delivers
     const int wbase = NW * half;                                // this workgroup's waves are wbase .. wbase + NW - 1
     unsigned *xr = PAIR ? p.xring + (size_t)b * p.NT * TC : nullptr;
     ALIGNER_STAMP(0);
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
 
     // wave 0's ghost lane replays "row -1": max_neg_val for every frame (core.pyx:27)
     for (int i = tid; i < RING_T * RING_LD; i += NW * 128) ring[i] = p.neg;
-    if (tid == 0) flagp[0] = 0;
+    if (tid == 0) { flagp[0] = 0; flagp[1] = 0; }
     __syncthreads();
 
     if (!p.force_exact) {
@@ -939,8 +943,12 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
                                 if (__builtin_expect(__ballot(cur == XRING_EMPTY) != 0ull, 0) && !xdead) {
                                     int spins = 0;
                                     do {
-                                        if (++spins > XRING_SPIN_LIMIT) {    // (cannot happen: the other half never waits)
-                                            if (lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+                                        if (++spins > XRING_SPIN_LIMIT) {
+                                            // the first half never waits for this one, but nothing promises that it
+                                            // has been dispatched: workgroups are dealt to eight XCDs with their own
+                                            // dispatchers, and other streams' kernels may hold the CU it is queued
+                                            // for.  Give up for good: the utterance's outputs become all-zero (below)
+                                            if (lane == 0) { atomicOr(p.status, ALIGNER_ST_INTERNAL); flagp[1] = 1; }
                                             xdead = true;
                                             break;
                                         }
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         if (tid == 0) {
             int v, spins = 0;
             while ((v = __hip_atomic_load(p.xflag + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == (int)XRING_EMPTY) {
-                if (++spins > XRING_SPIN_LIMIT) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
+                if (++spins > XRING_SPIN_LIMIT) { atomicOr(p.status, ALIGNER_ST_INTERNAL); flagp[1] = 1; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
             if (v == 2) flagp[0] = 1;
@@ -1140,6 +1148,13 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         // (thread 0's acquire has invalidated this CU's L1 and the XCD's L2 for everybody; the barrier orders the
         // other waves' loads behind it -- a full fence by all eight waves here cost the kernel 2 us)
         __syncthreads();
+        if (flagp[1] != 0) {
+            // gave up waiting for the first half (ALIGNER_ST_INTERNAL is set): a defined result instead of a path
+            // walked over filler -- all-zero path, zero durations, no token on any frame
+            __syncthreads();
+            write_degenerate<MASKMODE, VT>(p, b, MODE_EMPTY, tx, ty, reinterpret_cast<int *>(smem));
+            return;
+        }
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
     // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
@@ -1407,6 +1422,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     // [8,300,1536] 49 / 48; [16,400,2000] 65 / 75, [32,400,2000] 68 / 75, [64,400,2000] 74 / 76, [64,500,2048] 79 / 79:
     // taken from 56 tiles on, for batches of at most an eighth of the CU count.
     if (!(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_ONE_CU)) && nw_need > 4 && nw_need <= 8 && vec &&
+        2 * B <= device_cu_count() &&      // both halves of every utterance resident at once (see the kernel)
         ((flags & ALIGNER_F_TWO_CUS) || (8 * B <= device_cu_count() && L.NT >= 56))) {
         const size_t fwd = align_up(((size_t)4 * (2 * 64 * TILE_LD + RING_T * RING_LD) + RING_T * RING_LD) * 4 + 16, 16);
         p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
@@ -1685,6 +1701,10 @@ int aligner_maxpath_host_f32(int32_t *paths, float *values, const int32_t *t_xs,
                                  d_ws, wsb, B, Tx, Ty, max_neg_val, flags, nullptr);
     HOST_TRY(hipMemcpy(paths, d_path, n * 4, hipMemcpyDeviceToHost));
     if (flags & ALIGNER_F_WRITE_Q) HOST_TRY(hipMemcpy(values, d_val, n * 4, hipMemcpyDeviceToHost));
+    int st = 0;
+    HOST_TRY(hipMemcpy(&st, d_ws, sizeof(int), hipMemcpyDeviceToHost));
+    if (rc == ALIGNER_OK && (st & ALIGNER_ST_INTERNAL))
+        rc = fail(ALIGNER_EHIP, "internal consistency check failed on the device (status word %d): results are not valid", st);
 #undef HOST_TRY
     if (d_val) (void)hipFree(d_val);
     if (d_path) (void)hipFree(d_path);

@@ -12,6 +12,7 @@ CPU tensors are staged through the GPU and the call raises if no GPU is visible.
 """
 from __future__ import annotations
 
+import os
 from typing import NamedTuple, Optional
 
 import numpy as np
@@ -29,6 +30,7 @@ _TORCH_TO_DT = {
 _SCORE_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
 _workspaces = _lib.StreamWorkspaces(zero=True)     # status word: zero at allocation, sticky afterwards
+_CHECK_DEFAULT = os.environ.get("ALIGNER_AMD_CHECK", "") not in ("", "0")
 
 
 class Alignment(NamedTuple):
@@ -63,7 +65,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           max_neg_val: float = -1e9, compat_tx_gt_ty: bool = False,
           force_generic: bool = False, no_prev_table: bool = False, stream_path: bool = False,
           cus_per_utterance: Optional[int] = None,
-          out_path: Optional[torch.Tensor] = None) -> Alignment:
+          out_path: Optional[torch.Tensor] = None, check: Optional[bool] = None, _test_flags: int = 0) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
     value [B,Tx,Ty] float (computed in fp32 like the reference, __init__.py:14; fp32, bf16 and fp16 tensors are
@@ -75,6 +77,10 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
     are in flight on the GPU and nothing reads the path back at once).
     cus_per_utterance: None = the library decides (long text on a long mel axis in a small batch runs as two
     workgroups per utterance, ALIGNER_F_ONE_CU / ALIGNER_F_TWO_CUS otherwise); the results do not depend on it.
+    check: wait for the call and raise RuntimeError if the device's status word reports ALIGNER_ST_INTERNAL
+    (an internal consistency check failed: e.g. the two-workgroup form gave up waiting for its other half --
+    the outputs of that utterance are then all-zero, never a wrong path).  Default: the environment variable
+    ALIGNER_AMD_CHECK=1, else off -- the call stays asynchronous, and read_status() reports the bit later.
     """
     if cus_per_utterance not in (None, 1, 2):
         raise ValueError("cus_per_utterance must be None, 1 or 2")
@@ -144,7 +150,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     (_lib.F_FORCE_GENERIC if force_generic else 0) | \
                     (_lib.F_NO_PREV_TABLE if no_prev_table else 0) | \
                     (_lib.F_STREAM_PATH if stream_path else 0) | \
-                    (_lib.F_ONE_CU if cus_per_utterance == 1 else _lib.F_TWO_CUS if cus_per_utterance == 2 else 0)
+                    (_lib.F_ONE_CU if cus_per_utterance == 1 else _lib.F_TWO_CUS if cus_per_utterance == 2 else 0) | \
+                    int(_test_flags)
             _lib.check(lib.aligner_maxpath(
                 v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
                 ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))
@@ -154,7 +161,25 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     t.zero_()
         if want_path and out_path is None and path.dtype != (path_dtype or value.dtype):
             path = path.to(path_dtype or value.dtype)
+        if check is None:
+            check = _CHECK_DEFAULT
+        if check and B > 0 and Tx > 0 and Ty > 0:
+            st = _status_of(ws, device)
+            if st & _lib.ST_INTERNAL:
+                raise RuntimeError(f"aligner_amd: internal consistency check failed on {device} (status word {st}); "
+                                   "the affected utterances were returned all-zero")
     return Alignment(path, tok, dur)
+
+
+def _status_of(ws: torch.Tensor, device: torch.device) -> int:
+    """Blocking read of one workspace's status word WITHOUT clearing it (read_status() still sees the bits)."""
+    torch.cuda.current_stream(device).synchronize()
+    return int(ws[:4].view(torch.int32).item())
+
+
+def release_workspaces(device=None, stream=None) -> None:
+    """Free the scratch buffers align()/maximum_path() keep per (device, stream); see _lib.StreamWorkspaces."""
+    _workspaces.release(device, stream)
 
 
 def read_status(device=None) -> int:

@@ -75,9 +75,17 @@ extern "C" {
                                       own CU: same results, the sweep bound by two CUs' vector units instead of
                                       one's (long-form [8,500,4000]: 134 -> 106 us).  The boundary row between the
                                       halves travels through the workspace, which is why the call then starts
-                                      with a small fill kernel on the same stream */
+                                      with a small fill kernel on the same stream.  Only taken when all 2B workgroups
+                                      fit the chip at once; the second half's waits are bounded, and if the first half
+                                      did not deliver in time (other work kept it off the GPU for ~0.3 s) the
+                                      utterance comes back with an all-zero path, zero durations and
+                                      ALIGNER_ST_INTERNAL in the status word -- check it (aligner_maxpath_read_status;
+                                      aligner_maxpath_host_f32 does and fails with ALIGNER_EHIP) */
 #define ALIGNER_F_TWO_CUS      512 /* take the two-workgroup form whenever the text has 253..504 rows, whatever
                                       the batch size and mel length (testing; a short sweep loses by it) */
+#define ALIGNER_F_TEST_DROP_FIRST_HALF 1024 /* testing: in the two-workgroup form the first half of every utterance leaves
+                                      without delivering, so the second gives up after its bounded wait: all-zero
+                                      path, zero durations, ALIGNER_ST_INTERNAL -- the defined failure of that form */
 #define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside
                                       the band, in place, exactly as the reference does (core.pyx:18,30:
                                       `value[x, y] = max(v_cur, v_prev) + value[x, y]`).  Takes the

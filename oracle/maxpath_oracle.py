@@ -179,7 +179,7 @@ def path_from_tok(tok: np.ndarray, t_x_pad: int, t_y_pad: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- #
-# The real reference (authoring container; the .so also travels to the GPU box)
+# The real reference (authoring container only: oracle/_ref is git- AND gpurun-ignored)
 # --------------------------------------------------------------------------- #
 def load_ref():
     """Return the compiled reference extension module (oracle/_ref/core.so) or None."""

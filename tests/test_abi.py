@@ -97,6 +97,23 @@ def test_product_never_imports_the_oracle():
                         if re.search(r"^\s*(from|import)\s+.*oracle", line) or "maxpath_oracle" in line \
                                 or "libmaxpath_oracle" in line:
                             bad.append((fn, line.strip()))
+    # bench.py: the oracle may only be imported inside cpu_baseline() (the reported CPU leg, after the timed region)
+    import ast
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        src = f.read()
+    tree = ast.parse(src)
+    allowed = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in ("cpu_baseline", "cpu_baseline_boundary_search"):
+            allowed.update(id(n) for n in ast.walk(node))
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.Import, ast.ImportFrom)) and id(node) not in allowed:
+            names = [a.name for a in node.names] + [getattr(node, "module", None) or ""]
+            if any("oracle" in n for n in names):
+                bad.append(("bench.py", ast.get_source_segment(src, node)))
+        if isinstance(node, ast.Constant) and isinstance(node.value, str) and id(node) not in allowed:
+            if "libmaxpath_oracle" in node.value or "oracle/_ref" in node.value:
+                bad.append(("bench.py", node.value[:60]))
     assert not bad, bad
 
 

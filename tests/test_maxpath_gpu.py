@@ -541,8 +541,9 @@ def test_two_workgroups_full_size_long_form(appendix_a, dev):
 
 
 def test_two_workgroups_in_a_replayed_graph(dev):
-    """The two-workgroup form starts its launch by refilling the boundary ring (hipMemsetAsync on the caller's stream):
-    captured into a HIP graph with the kernels, so a replay on NEW scores in the same buffers must not meet the
+    """The two-workgroup form starts its launch by refilling the boundary ring (xring_fill_kernel on the caller's stream --
+    a hipMemsetAsync node did not refill it on replay): captured into a HIP graph with the kernels, so a replay on NEW
+    scores in the same buffers must not meet the
     previous replay's boundary rows.  C ABI straight, as a serving loop would drive it."""
     from aligner_amd import _lib
     lib = _lib.load()
@@ -579,3 +580,88 @@ def test_two_workgroups_in_a_replayed_graph(dev):
     st = np.zeros(1, np.int32)
     _lib.check(lib.aligner_maxpath_read_status(ws.data_ptr(), st.ctypes.data, None))
     assert int(st[0]) == 0
+
+
+def test_two_workgroups_beside_other_work(dev):
+    """The second workgroup of an utterance waits for the first through the workspace.  Run the form while other
+    streams keep the CUs busy (a stream of alignment batches that occupy every CU, and a second two-workgroup launch
+    on a third stream): the waits are bounded and either half may be scheduled late -- every result must still be the
+    oracle's and the status word clean."""
+    import aligner_amd
+    rng = np.random.default_rng(77)
+    B, Tx, Ty = 6, 420, 1800
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([420, 400, 300, 420, 260, 333], np.int32); ty = np.array([1800, 1700, 1800, 900, 1800, 1500], np.int32)
+    want = _oracle_path(v, tx, ty)
+    d_v, d_tx, d_ty = torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    # the load: [512,200,1000] batches, one workgroup per utterance on every CU, and a large elementwise kernel
+    big = torch.from_numpy(synth.synth_value(512, 200, 1000, 3)).to(dev)
+    btx = torch.full((512,), 200, dtype=torch.int32, device=dev); bty = torch.full((512,), 1000, dtype=torch.int32, device=dev)
+    s_load, s_a, s_b = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(s_load):
+            for _ in range(4):
+                aligner_amd.align(big, btx, bty, want_path=False)
+                big2 = big * 1.0001
+        with torch.cuda.stream(s_a):
+            outs.append(aligner_amd.align(d_v, d_tx, d_ty, path_dtype=torch.int32, cus_per_utterance=2))
+        with torch.cuda.stream(s_b):
+            outs.append(aligner_amd.align(d_v, d_tx, d_ty, path_dtype=torch.int32, cus_per_utterance=2))
+    torch.cuda.synchronize()
+    for k, r in enumerate(outs):
+        assert np.array_equal(r.path.cpu().numpy(), want), k
+        assert np.array_equal(r.durations.cpu().numpy(), want.sum(2)), k
+    assert aligner_amd.read_status(dev) == 0
+    del big2
+
+
+def test_two_workgroups_first_half_never_delivers(dev):
+    """The defined failure of the two-workgroup form: if the first half does not deliver (here: switched off by the
+    test flag), the second gives up after its bounded wait -- the utterance comes back all-zero with ALIGNER_ST_INTERNAL
+    in the status word, align(check=True) raises, and maximum_path_c's host form returns an error.  Utterances that
+    never needed a second workgroup are untouched."""
+    import aligner_amd
+    from aligner_amd import _lib
+    rng = np.random.default_rng(5)
+    B, Tx, Ty = 3, 300, 640
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([300, 200, 280], np.int32); ty = np.array([640, 600, 640], np.int32)     # utterance 1: one workgroup
+    want = _oracle_path(v, tx, ty)
+    assert aligner_amd.read_status(dev) == 0
+    p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=2, _test_flags=_lib.F_TEST_DROP_FIRST_HALF)
+    assert aligner_amd.read_status(dev) & _lib.ST_INTERNAL
+    for b in (0, 2):
+        assert not p[b].any() and not dur[b].any() and np.all(tok[b] == -1)
+    assert np.array_equal(p[1], want[1]) and np.array_equal(dur[1], want[1].sum(1))
+    with pytest.raises(RuntimeError, match="internal consistency"):
+        aligner_amd.align(torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
+                          cus_per_utterance=2, _test_flags=_lib.F_TEST_DROP_FIRST_HALF, check=True)
+    assert aligner_amd.read_status(dev) & _lib.ST_INTERNAL           # check=True does not clear the word
+    # the blocking host form (maximum_path_c's contract) reports it as an error
+    lib = _lib.load()
+    paths = np.zeros((B, Tx, Ty), np.int32)
+    vals = v.copy()
+    rc = lib.aligner_maxpath_host_f32(paths.ctypes.data, vals.ctypes.data, tx.ctypes.data, ty.ctypes.data, B, Tx, Ty, -1e9,
+                                      _lib.F_TWO_CUS | _lib.F_TEST_DROP_FIRST_HALF)
+    assert rc == -5 and b"internal consistency" in lib.aligner_last_error()
+    # and the next call is fine again
+    p, _, _ = _hip(v, tx, ty, dev, cus_per_utterance=2)
+    assert np.array_equal(p, want) and aligner_amd.read_status(dev) == 0
+
+
+def test_workspace_regrowth_keeps_the_status_word(dev):
+    """A workspace that has to grow is replaced; the sticky status bits raised through the old one must survive
+    until read_status() (StreamWorkspaces.get carries the word over on the stream)."""
+    import aligner_amd
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        v = torch.zeros((2, 4, 8), device=dev)
+        aligner_amd.align(v, torch.tensor([0, 3]), torch.tensor([8, 8]))               # t_x = 0: ALIGNER_ST_BAD_LENGTHS
+        big = torch.zeros((4, 300, 2000), device=dev)
+        aligner_amd.align(big, torch.full((4,), 300), torch.full((4,), 2000))          # same stream, larger workspace
+    torch.cuda.synchronize()
+    assert aligner_amd.read_status(dev) & 1
+    assert aligner_amd.read_status(dev) == 0
+    aligner_amd.maxpath.release_workspaces(dev, s.cuda_stream)
