@@ -26,6 +26,8 @@ F_STREAM_PATH = 128
 F_ONE_CU = 256
 F_TWO_CUS = 512
 F_TEST_DROP_FIRST_HALF = 1024
+F_PATH_PREZEROED = 2048
+F_SEPARATE_EXPAND = 4096
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2
@@ -54,6 +56,8 @@ SIGNATURES = {
                                          _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_expand": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "aligner_maxpath_expand_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "aligner_maxpath_zero_path": (_i, [_vp, _i, _i, _i, _i, _i, _vp]),
+    "aligner_maxpath_scatter_path": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "aligner_maxpath_read_status": (_i, [_vp, _vp, _vp]),
     "aligner_debug_set_stamps": (None, [_vp]),
     "aligner_debug_set_option": (_i, [_c.c_char_p, _i]),

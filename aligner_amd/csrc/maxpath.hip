@@ -88,6 +88,13 @@ struct MaxpathParams {
     int         *xflag;     // ... [B] first half done (1; 2 = it met a non-finite score), 0xFFFFFFFF until then
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable; [2B] when utterances are split)
     float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
+    void        *path1;     // ALIGNER_F_PATH_PREZEROED: the caller's all-zero dense path; the kernel writes its ones (nullable)
+    int          path1_es;  // ... element size in bytes (1, 2, 4, 8)
+    unsigned long long path1_one;   // ... the bits of a 1 in that dtype
+    int          zero_blocks;   // the launch's first `zero_blocks` workgroups write the path's zeros while the others search (0: none)
+    int          zero_nt;       // ... with non-temporal stores
+    unsigned long long zero_n16;    // ... 16-byte pieces of the path
+    int         *zsync;         // ... workspace: [0] zero workgroups done, [1] workgroups finished (both 0 between launches)
 };
 
 // Development aid: lane 0 of every wave drops a shader-clock stamp (slot 6/7 the
@@ -99,6 +106,8 @@ struct MaxpathParams {
             p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (k)] =                \
                 ((k) == 6 || (k) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();   \
     } while (0)
+
+constexpr int ZERO_SPIN_LIMIT = 1 << 22;           // polls of the zero-fill count before ALIGNER_ST_INTERNAL (seconds)
 
 // --------------------------------------------------------------------------
 // small device helpers
@@ -181,7 +190,28 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
     for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
         for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
-    if (!p.tok) return;
+    if (!p.tok && !p.path1) return;
+    // core.pyx:33 `path[index, y] = 1` on a path the caller zeroed (np.zeros, __init__.py:15): one element per frame
+    auto mark_path = [&](int t, int y) {
+        const size_t idx = ((size_t)b * p.Tx + t) * p.Ty + y;
+        switch (p.path1_es) {
+            case 1: static_cast<unsigned char *>(p.path1)[idx] = (unsigned char)p.path1_one; break;
+            case 2: static_cast<unsigned short *>(p.path1)[idx] = (unsigned short)p.path1_one; break;
+            case 4: static_cast<unsigned *>(p.path1)[idx] = (unsigned)p.path1_one; break;
+            default: static_cast<unsigned long long *>(p.path1)[idx] = p.path1_one; break;
+        }
+    };
+    if (p.path1 && p.zero_blocks > 0) {
+        // the zeros come from the launch's zero workgroups: all of them must have reported before a 1 is written
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(p.zsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.zero_blocks) {   // (relaxed: see the kernel)
+                if (++spins > ZERO_SPIN_LIMIT) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+    }
     const int nmw = (ty + 31) >> 5;                        // words of the bit string
     unsigned *mark = reinterpret_cast<unsigned *>(startsL + starts_words_of(p.Tx));
     int *before = reinterpret_cast<int *>(mark + nmw);    // set bits in the words before word j
@@ -212,7 +242,8 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
         for (int y = tid; y < p.Ty; y += nthreads) {
             int t = -1;
             if (y < ty) t = before[y >> 5] + __builtin_popcount(mark[y >> 5] & ((2u << (y & 31)) - 1u));
-            p.tok[(size_t)b * p.Ty + y] = t;
+            if (p.tok) p.tok[(size_t)b * p.Ty + y] = t;
+            if (p.path1 && t >= 0) mark_path(t, y);
         }
     } else {
         for (int y = tid; y < p.Ty; y += nthreads) {
@@ -225,7 +256,8 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
                 }
                 t = lo;
             }
-            p.tok[(size_t)b * p.Ty + y] = t;
+            if (p.tok) p.tok[(size_t)b * p.Ty + y] = t;
+            if (p.path1 && t >= 0) mark_path(t, y);
         }
     }
 }
@@ -750,14 +782,14 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
 constexpr unsigned XRING_EMPTY = 0xFFFFFFFFu;
 constexpr int XRING_SPIN_LIMIT = 1 << 18;          // polls before giving up for good with ALIGNER_ST_INTERNAL (~0.3 s)
 
-template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT, bool PAIR = false>
-__global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
+template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT, bool PAIR>
+__device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, const int blk) {
     static_assert(!PAIR || NW == 4, "the split form is built on the four-wave workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = PAIR ? (int)(blockIdx.x >= (unsigned)p.B) : 0;
-    const int b = PAIR ? (int)blockIdx.x - half * p.B : (int)blockIdx.x;
+    const int half = PAIR ? (int)(blk >= p.B) : 0;
+    const int b = PAIR ? blk - half * p.B : blk;
     int tx, ty;
     const int mode = classify_lengths(p, b, tx, ty);
     if (mode != MODE_NORMAL) {
@@ -1167,6 +1199,52 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     ALIGNER_STAMP(7);
 }
 
+// The launch.  With p.zero_blocks the grid is zero_blocks + B workgroups: the first ones -- on the CUs a batch of B
+// utterances leaves idle -- write the zeros of the dense path (np.zeros, __init__.py:15) while the others search, and
+// an utterance's workgroup writes its ones (core.pyx:33) once the zero workgroups have reported (store_outputs):
+// the dense path costs no launch of its own and nothing on the step's serial chain.  (A second stream or graph
+// branch for the zeros was measured first: the kernels overlap as hoped, but a forked HIP graph costs 15-20 us per
+// replay on this stack.)  Zero workgroups never wait, and they come first in dispatch order.
+template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT, bool PAIR = false>
+__global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
+    const int Z = PAIR ? 0 : p.zero_blocks;
+    if (!PAIR && (int)blockIdx.x < Z) {
+        // Agent-scope stores (sc1: written through this XCD's L2), then wait for them, then a RELAXED count: no
+        // release / acquire anywhere.  A release at agent scope writes the whole L2 back and an acquire invalidates it --
+        // per workgroup, under the other workgroups' sweeps: the first version of this, with a fence and a release
+        // increment per zero workgroup and an acquire poll per utterance, took 96 us instead of 33.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 *d = reinterpret_cast<u32x4 *>(p.path1);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        const unsigned long long per = (p.zero_n16 + Z - 1) / Z;
+        const unsigned long long lo = per * blockIdx.x, hi = lo + per < p.zero_n16 ? lo + per : p.zero_n16;
+        if (p.zero_nt) {
+            for (unsigned long long i = lo + threadIdx.x; i < hi; i += NW * 128)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(d + i), "v"(z) : "memory");
+        } else {
+            for (unsigned long long i = lo + threadIdx.x; i < hi; i += NW * 128)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(d + i), "v"(z) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's zeros have left for memory ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.zsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the workgroup says so
+    } else {
+        maxpath_pipelined_body<NW, DEPTH, VEC, MASKMODE, VT, PAIR>(p, (int)blockIdx.x - Z);
+    }
+    if (!PAIR && Z > 0) {
+        // the last workgroup to finish leaves both counters at 0 for the next launch (launches that share a workspace
+        // are ordered on their stream)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int f = __hip_atomic_fetch_add(p.zsync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (f == Z + p.B - 1) {
+                __hip_atomic_store(p.zsync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.zsync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
 #include "fused_align.inc"
 
 // --------------------------------------------------------------------------
@@ -1295,7 +1373,7 @@ static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStrea
 
 template <int NW, int DEPTH>
 static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, size_t lds, hipStream_t s) {
-    dim3 grid(p.B), block(NW * 128);
+    dim3 grid(p.B + p.zero_blocks), block(NW * 128);
     if (vt != VT_F32) {
         // 16-bit scores: 16-byte loaders only (the caller routes everything else to the generic kernel),
         // and only the two wide workgroup shapes are built (narrow text runs on NW = 4 with idle waves)
@@ -1351,9 +1429,27 @@ static int launch_generic(MaxpathParams p, int maskmode, int vt, size_t lds, hip
     return launch_generic_vt<R, VT_F32>(p, maskmode, lds, s);
 }
 
+static void set_path_ones(MaxpathParams &p, void *path, int path_dtype) {
+    p.path1 = path;
+    p.path1_es = dtype_size(path_dtype);
+    switch (path_dtype) {
+        case ALIGNER_DT_F32: p.path1_one = 0x3F800000ull; break;
+        case ALIGNER_DT_F64: p.path1_one = 0x3FF0000000000000ull; break;
+        case ALIGNER_DT_F16: p.path1_one = 0x3C00ull; break;
+        case ALIGNER_DT_BF16: p.path1_one = 0x3F80ull; break;
+        default: p.path1_one = 1ull; break;
+    }
+}
+
 static int forward_impl(const void *value, int value_dtype, const void *mask, int mask_dtype, const int32_t *t_xs,
                         const int32_t *t_ys, int32_t *tok_out, int32_t *dur_out, void *ws,
-                        size_t ws_bytes, int B, int Tx, int Ty, float neg, int flags, hipStream_t s) {
+                        size_t ws_bytes, int B, int Tx, int Ty, float neg, int flags, hipStream_t s,
+                        void *path_out = nullptr, int path_dtype = 0, bool path_is_zero = false, bool *path_done = nullptr) {
+    // path_out: the dense path this launch may finish itself -- its ones always (path_is_zero: the caller's zeros,
+    // ALIGNER_F_PATH_PREZEROED), its zeros too where the pipelined kernel runs with zero workgroups; *path_done says
+    // whether it did (otherwise the caller launches expand)
+    if (path_done) *path_done = false;
+    void *path_prezeroed = path_is_zero ? path_out : nullptr;
     if (!value || !ws) return fail(ALIGNER_EINVAL, "value/workspace pointer is null");
     if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
     if ((size_t)Tx * (size_t)Ty >= (1ull << 31))
@@ -1396,6 +1492,11 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.stamps = g_debug_stamps;
     p.dump = nullptr;
     p.qout = nullptr;
+    p.path1 = nullptr; p.path1_es = 0; p.path1_one = 0;
+    if (path_prezeroed) set_path_ones(p, path_prezeroed, path_dtype);
+    p.zero_blocks = 0; p.zero_nt = 0; p.zero_n16 = 0;
+    p.zsync = reinterpret_cast<int *>(wsb + L.status_off + 16);
+    if (path_prezeroed && path_done) *path_done = true;
     p.xring = reinterpret_cast<unsigned *>(wsb + L.xring_off);
     p.xflag = reinterpret_cast<int *>(wsb + L.xring_off + (size_t)B * L.NT * TC * sizeof(unsigned));
     if (flags & ALIGNER_F_WRITE_Q) {
@@ -1464,6 +1565,17 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                 }
             }
             if (lds) {
+                // the dense path inside this launch: zero workgroups on the CUs the batch leaves idle (see the kernel)
+                const int cus = device_cu_count();
+                const size_t pbytes = path_out ? (size_t)B * Tx * Ty * dtype_size(path_dtype) : 0;
+                if (path_out && !path_is_zero && !(flags & ALIGNER_F_SEPARATE_EXPAND) && cus - B >= 32 &&
+                    (reinterpret_cast<uintptr_t>(path_out) & 15) == 0 && pbytes % 16 == 0 && dtype_size(path_dtype) > 0) {
+                    p.zero_blocks = cus - B;
+                    p.zero_nt = (flags & ALIGNER_F_STREAM_PATH) ? 1 : 0;
+                    p.zero_n16 = pbytes / 16;
+                    set_path_ones(p, path_out, path_dtype);
+                    if (path_done) *path_done = true;
+                }
                 switch (NW) {
                     case 1: return launch_pipelined<1, 4>(p, vec, maskmode, vt, lds, s);
                     case 2: return launch_pipelined<2, 4>(p, vec, maskmode, vt, lds, s);
@@ -1501,6 +1613,55 @@ static int launch_expand(const int *starts, void *path, int B, int Tx, int Ty, T
         hipLaunchKernelGGL((expand_kernel<T, true, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
     else
         hipLaunchKernelGGL((expand_kernel<T, false, false>), grid, block, 0, s, starts, static_cast<T *>(path), Tx, Ty, rpb, one);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+// --------------------------------------------------------------------------
+// The dense path the way the reference builds it: np.zeros (__init__.py:15), then core.pyx:33's `path[index, y] = 1`.
+// The zeros do not depend on the alignment, so a caller with a second stream (or a graph branch) writes them
+// WHILE the search runs, and all that is left behind the search are t_y stores per utterance -- the 51 MB write of
+// expand_kernel leaves the serial chain of a step (bench.py: one batch at a time).
+// --------------------------------------------------------------------------
+template <bool STREAM>
+__global__ __launch_bounds__(256) void zero_path_kernel(uint4 *__restrict__ dst, size_t n16, unsigned char *__restrict__ tail,
+                                                         int ntail) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    u32x4 *d = reinterpret_cast<u32x4 *>(dst);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        if (STREAM) __builtin_nontemporal_store(z, d + i);
+        else d[i] = z;
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+// one thread per frame: the token whose [start, next start) holds it (bisection over the starts, staged in LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_path_kernel(const int *__restrict__ starts, T *__restrict__ path, int Tx, int Ty,
+                                                            T one) {
+    extern __shared__ int st[];                                    // [Tx + 1]
+    const int b = blockIdx.y, y = blockIdx.x * 256 + threadIdx.x;
+    const int *sb = starts + (size_t)b * (Tx + 1);
+    for (int x = threadIdx.x; x <= Tx; x += 256) st[x] = sb[x];
+    __syncthreads();
+    if (y >= Ty || y >= st[Tx] || y < st[0]) return;               // past the utterance's last frame: no token
+    int lo = 0, hi = Tx;                                           // invariant: st[lo] <= y < st[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (st[mid] <= y) lo = mid;
+        else hi = mid;
+    }
+    path[((size_t)b * Tx + lo) * Ty + y] = one;
+}
+
+template <typename T>
+static int launch_scatter(const int *starts, void *path, int B, int Tx, int Ty, T one, hipStream_t s) {
+    const size_t lds = (size_t)(Tx + 1) * sizeof(int);
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(scatter_path_kernel<T>), lds));
+    hipLaunchKernelGGL(scatter_path_kernel<T>, dim3((Ty + 255) / 256, B), dim3(256), lds, s, starts, static_cast<T *>(path),
+                       Tx, Ty, one);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
@@ -1591,6 +1752,57 @@ int aligner_maxpath_expand_ex(const void *ws, void *path, int path_dtype, int B,
                        static_cast<hipStream_t>(stream));
 }
 
+int aligner_maxpath_zero_path(void *path, int path_dtype, int B, int Tx, int Ty, int flags, void *stream) {
+    if (!path) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
+    const int es = dtype_size(path_dtype);
+    if (es == 0) return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    if (B == 0) return ALIGNER_OK;
+    unsigned char *pb = static_cast<unsigned char *>(path);
+    const size_t bytes = (size_t)B * Tx * Ty * es;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // 16-byte stores over the aligned middle, byte stores for what is left at either end (< 16 bytes each)
+    const size_t head = (16 - (reinterpret_cast<uintptr_t>(pb) & 15)) & 15;
+    const size_t h = head < bytes ? head : bytes;
+    const size_t n16 = (bytes - h) / 16, tail = (bytes - h) - n16 * 16;
+    if (h) {
+        hipLaunchKernelGGL(zero_path_kernel<false>, dim3(1), dim3(256), 0, s, reinterpret_cast<uint4 *>(pb), (size_t)0, pb, (int)h);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    size_t blocks = (n16 + 255) / 256;
+    const size_t cap = (size_t)device_cu_count() * 16;
+    blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+    if (flags & ALIGNER_F_STREAM_PATH)
+        hipLaunchKernelGGL(zero_path_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(pb + h), n16,
+                           pb + h + n16 * 16, (int)tail);
+    else
+        hipLaunchKernelGGL(zero_path_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(pb + h), n16,
+                           pb + h + n16 * 16, (int)tail);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+int aligner_maxpath_scatter_path(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty, void *stream) {
+    if (!ws || !path) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
+    if (B == 0) return ALIGNER_OK;
+    if (B > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    if ((size_t)(Tx + 1) * sizeof(int) > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "Tx=%d too large", Tx);
+    const WsLayout L = ws_layout(B, Tx, Ty);
+    const int *starts = reinterpret_cast<const int *>(static_cast<const unsigned char *>(ws) + L.starts_off);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (path_dtype) {
+        case ALIGNER_DT_F32: return launch_scatter<float>(starts, path, B, Tx, Ty, 1.0f, s);
+        case ALIGNER_DT_F64: return launch_scatter<double>(starts, path, B, Tx, Ty, 1.0, s);
+        case ALIGNER_DT_I32: return launch_scatter<int32_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_I64: return launch_scatter<int64_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_U8:  return launch_scatter<uint8_t>(starts, path, B, Tx, Ty, 1, s);
+        case ALIGNER_DT_F16: return launch_scatter<uint16_t>(starts, path, B, Tx, Ty, 0x3C00, s);
+        case ALIGNER_DT_BF16: return launch_scatter<uint16_t>(starts, path, B, Tx, Ty, 0x3F80, s);
+        default: return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    }
+}
+
 int aligner_maxpath_expand(const void *ws, void *path, int path_dtype, int B, int Tx, int Ty,
                            void *stream) {
     return aligner_maxpath_expand_ex(ws, path, path_dtype, B, Tx, Ty, 0, stream);
@@ -1602,9 +1814,13 @@ int aligner_maxpath(const void *value, int value_dtype, const void *mask, int ma
                     float max_neg_val, int flags, void *stream) {
     if (path_out && dtype_size(path_dtype) == 0)
         return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    // ALIGNER_F_PATH_PREZEROED: the search kernel itself writes the ones into the caller's zeros -- no expand launch
+    // and without it the pipelined kernel's own zero workgroups do the whole path where they can (path_done)
+    const bool prez = path_out && (flags & ALIGNER_F_PATH_PREZEROED);
+    bool path_done = false;
     int rc = forward_impl(value, value_dtype, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
-                          max_neg_val, flags, static_cast<hipStream_t>(stream));
-    if (rc || !path_out || B == 0) return rc;
+                          max_neg_val, flags, static_cast<hipStream_t>(stream), path_out, path_dtype, prez, &path_done);
+    if (rc || !path_out || B == 0 || path_done) return rc;
     return aligner_maxpath_expand_ex(ws, path_out, path_dtype, B, Tx, Ty, flags, stream);
 }
 
@@ -1645,6 +1861,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     p.stamps = g_debug_stamps;
     p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
     p.qout = nullptr;
+    p.path1 = nullptr; p.path1_es = 0; p.path1_one = 0;
     p.xring = nullptr; p.xflag = nullptr;
     const size_t lds_max = (size_t)lds_limit();
     const FusedLds FL = fused_lds_layout();

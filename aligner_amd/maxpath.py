@@ -65,7 +65,8 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
           max_neg_val: float = -1e9, compat_tx_gt_ty: bool = False,
           force_generic: bool = False, no_prev_table: bool = False, stream_path: bool = False,
           cus_per_utterance: Optional[int] = None,
-          out_path: Optional[torch.Tensor] = None, check: Optional[bool] = None, _test_flags: int = 0) -> Alignment:
+          out_path: Optional[torch.Tensor] = None, out_path_is_zero: bool = False,
+          check: Optional[bool] = None, _test_flags: int = 0) -> Alignment:
     """Monotonic alignment search for a batch resident on the GPU.
 
     value [B,Tx,Ty] float (computed in fp32 like the reference, __init__.py:14; fp32, bf16 and fp16 tensors are
@@ -77,6 +78,9 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
     are in flight on the GPU and nothing reads the path back at once).
     cus_per_utterance: None = the library decides (long text on a long mel axis in a small batch runs as two
     workgroups per utterance, ALIGNER_F_ONE_CU / ALIGNER_F_TWO_CUS otherwise); the results do not depend on it.
+    out_path / out_path_is_zero: write the path into the caller's tensor; with out_path_is_zero the caller vouches
+    that it already holds zeros (e.g. written on another stream while the scores were computed): the search kernel
+    then writes only the ones (ALIGNER_F_PATH_PREZEROED) and the 4*B*Tx*Ty-byte expand pass is not launched.
     check: wait for the call and raise RuntimeError if the device's status word reports ALIGNER_ST_INTERNAL
     (an internal consistency check failed: e.g. the two-workgroup form gave up waiting for its other half --
     the outputs of that utterance are then all-zero, never a wrong path).  Default: the environment variable
@@ -151,6 +155,7 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     (_lib.F_NO_PREV_TABLE if no_prev_table else 0) | \
                     (_lib.F_STREAM_PATH if stream_path else 0) | \
                     (_lib.F_ONE_CU if cus_per_utterance == 1 else _lib.F_TWO_CUS if cus_per_utterance == 2 else 0) | \
+                    (_lib.F_PATH_PREZEROED if (out_path_is_zero and out_path is not None) else 0) | \
                     int(_test_flags)
             _lib.check(lib.aligner_maxpath(
                 v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),

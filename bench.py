@@ -43,6 +43,11 @@ class Step:
 
     def __init__(self, dev: torch.device, seed: int, use_graph: bool, stream_path: bool = False):
         self.dev = dev
+        # "branch": the dense path in the reference's own two steps (zeros, then ones: __init__.py:15, core.pyx:33) with the
+        # zeros on a second graph branch BESIDE the alignment search, so that only the ones follow it; "expand": one
+        # streaming kernel behind the search.  The one-batch-at-a-time figure uses the branch form.
+        self.path_mode = "expand"
+        self.side = torch.cuda.Stream(dev)
         # ALIGNER_F_STREAM_PATH: non-temporal stores for the dense path (pays with several batches in flight)
         self.expand_flags = _lib.F_STREAM_PATH if stream_path else 0
         self.lib = _lib.load()
@@ -83,10 +88,58 @@ class Step:
         _lib.check(self.lib.aligner_maxpath_expand_ex(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
                                                       self.expand_flags, self.stream()))
 
+    def zero_path(self):
+        _lib.check(self.lib.aligner_maxpath_zero_path(self.path.data_ptr(), _lib.DT_F32, B, TX, TY, self.expand_flags,
+                                                      self.stream()))
+
+    def scatter_path(self):
+        _lib.check(self.lib.aligner_maxpath_scatter_path(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
+                                                         self.stream()))
+
+    def forward_with_ones(self):
+        """The search with ALIGNER_F_PATH_PREZEROED: the kernel writes the path's ones into zeros that are already there."""
+        _lib.check(self.lib.aligner_maxpath_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(), self.t_y.data_ptr(),
+                                                self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
+                                                self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
+                                                -1e9, _lib.F_PATH_PREZEROED, self.stream()))
+
+    def search_with_path(self):
+        """aligner_maxpath_f32 as a caller uses it: ONE launch -- the search, and on the CUs the batch leaves idle the
+        zeros of the dense path; the utterances' workgroups write the ones."""
+        _lib.check(self.lib.aligner_maxpath_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(), self.t_y.data_ptr(),
+                                                self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
+                                                self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
+                                                -1e9, self.expand_flags, self.stream()))
+
     def eager(self):
+        if self.path_mode == "fused":
+            self.softattn()
+            self.search_with_path()
+            return
+        if self.path_mode == "inline":
+            # zeros (np.zeros of __init__.py:15) on a second branch BESIDE the similarity kernel -- whose first stores
+            # leave only after its 7 us prologue --, then the search writes its own ones (core.pyx:33): nothing of the
+            # dense path is left on the step's serial chain
+            cur = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.zero_path()
+            self.softattn()
+            cur.wait_stream(self.side)
+            self.forward_with_ones()
+            return
         self.softattn()
-        self.forward()
-        self.expand()
+        if self.path_mode == "branch":
+            cur = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(cur)                 # fork: the zeros need nothing of this step ...
+            with torch.cuda.stream(self.side):
+                self.zero_path()
+            self.forward()
+            cur.wait_stream(self.side)                 # ... join: the ones need the zeros and the search
+            self.scatter_path()
+        else:
+            self.forward()
+            self.expand()
 
     def capture(self):
         """Capture the three launches of a step into a HIP graph (launch-bound otherwise)."""
@@ -357,6 +410,13 @@ def main():
     ap.add_argument("--no-repeats", dest="repeats", action="store_false",
                     help="skip the four extra timed regions (spread) and the one-batch-in-flight figure")
     ap.add_argument("--no-stream-path", action="store_true", help="ordinary stores for the dense path in every run")
+    ap.add_argument("--path-mode", choices=["expand", "branch", "inline", "fused"], default="expand",
+                    help="dense path of the batches-in-flight run: one streaming kernel behind the search (expand), or zeros on a "
+                         "second graph branch beside the search + one 1 per frame behind it (branch).  The one-batch-at-a-time "
+                         "figure always takes the branch form (--serial-path-mode)")
+    ap.add_argument("--serial-path-mode", choices=["expand", "branch", "inline", "fused"], default="fused",
+                    help="inline: zeros beside the similarity kernel, the search kernel writes the ones itself "
+                         "(ALIGNER_F_PATH_PREZEROED)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
@@ -406,6 +466,8 @@ def main():
     stream_path = nstreams > 1 and not args.no_stream_path
     steps = [Step(dev, seed=1234 + 17 * rank + 1000 * i, use_graph=not args.no_graph, stream_path=stream_path)
              for i in range(nstreams)]
+    for st in steps:
+        st.path_mode = args.path_mode
     streams = [torch.cuda.Stream(dev) for _ in range(nstreams)]
     for st, strm in zip(steps, streams):
         with torch.cuda.stream(strm):
@@ -486,21 +548,30 @@ def main():
     extra = [timed(args.steps) for _ in range(4)] if args.repeats else []
     # strictly serial steps (one batch in flight: what a training step that waits for its alignment sees)
     serial_elapsed = None
+    serial_expand_elapsed = None
     if dist is None and args.repeats:
-        if stream_path:                                # one batch at a time: ordinary path stores (see above)
-            steps[0].expand_flags = 0
-            steps[0].capture()
+        # one batch at a time: ordinary path stores (see above), and the dense path as zeros on a second graph branch
+        # beside the alignment search + one 1 per frame behind it -- the 51 MB write is off the step's serial chain
+        steps[0].expand_flags = 0
+        steps[0].path_mode = args.serial_path_mode
+        steps[0].capture()
         run(min(args.warmup, 10), 1)
         serial_elapsed = float(np.median([timed(args.steps, 1) for _ in range(3)]))
-        if stream_path:
-            steps[0].expand_flags = _lib.F_STREAM_PATH
+        if args.serial_path_mode != "expand":          # for comparison: the same step with the one-kernel path
+            steps[0].path_mode = "expand"
             steps[0].capture()
+            run(min(args.warmup, 10), 1)
+            serial_expand_elapsed = float(np.median([timed(args.steps, 1) for _ in range(3)]))
+        steps[0].expand_flags = _lib.F_STREAM_PATH if stream_path else 0
+        steps[0].path_mode = args.path_mode
+        steps[0].capture()
 
     # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
     for st in steps:
         assert bool((st.tok[:, -1] == TX - 1).all())
         if dist is None:
             assert int(st.dur.sum().item()) == B * TY
+            assert bool((st.path.sum(2).to(torch.int32) == st.dur).all())       # the dense path IS those durations
     if dist is not None:
         filled = min(args.steps + args.warmup, ge)
         for bi in range(2):
@@ -515,12 +586,18 @@ def main():
         t_sim = event_time_us(step.softattn, it, dev)
         t_fwd = event_time_us(step.forward, it, dev)
         t_exp = event_time_us(step.expand, it, dev)
+        t_full = event_time_us(step.search_with_path, it, dev)
+        t_zero = event_time_us(step.zero_path, it, dev)
+        t_scat = event_time_us(step.scatter_path, it, dev)
         cells = B * TX * TY
         kernels = {
             "softattn_kernel": {"us": t_sim, "bytes": 4 * B * C_ATT * (TX + TY) + 4 * cells},
             "maxpath_pipelined_kernel": {"us": t_fwd, "bytes": 4 * cells + 4 * B * (TX + TY)},
             "expand_kernel": {"us": t_exp, "bytes": 4 * cells + 4 * B * TY},
         }
+        side = {"maxpath_pipelined_kernel (search + dense path in one launch)": {"us": t_full, "bytes": 8 * cells + 4 * B * (TX + TY)},
+                "zero_path_kernel": {"us": t_zero, "bytes": 4 * cells},
+                "scatter_path_kernel": {"us": t_scat, "bytes": 4 * B * TY + 4 * B * (TX + 1)}}
         dom = max(kernels, key=lambda k: kernels[k]["us"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
@@ -545,8 +622,10 @@ def main():
                     # resident rows) -- the memory bound of THIS launch is B x 64 GB/s, not the chip's peak
                     "launch_fetch_bound_GBps": round(min(B, 256) * 64.0, 1),
                     "all_kernels": {k: {"us": round(v["us"], 2),
-                                        "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)}
-                                    for k, v in kernels.items()}}
+                                        "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
+                                        "frac_of_8000": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
+                                        "frac_of_6300_achievable": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / 6300.0, 3)}
+                                    for k, v in {**kernels, **side}.items()}}
         out = {
             "metric": "aligned utterances/sec + frames/sec, [B=64,T_text=200,T_mel=1000]",
             "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * TY, 1),
@@ -556,6 +635,8 @@ def main():
                                     [round(x / args.steps * 1e3, 5) for x in extra]) if extra else None,
             "ms_per_step_median": round(float(np.median([elapsed] + extra)) / args.steps * 1e3, 5) if extra else None,
             "serial_ms_per_step": round(serial_elapsed / args.steps * 1e3, 5) if serial_elapsed else None,
+            "serial_ms_per_step_expand_kernel": (round(serial_expand_elapsed / args.steps * 1e3, 5)
+                                                 if serial_expand_elapsed else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: similarity (L2, C=80) + monotonic alignment search, "
@@ -565,6 +646,11 @@ def main():
                        "batches_in_flight": nstreams,
                        "path_stores": ("non-temporal (ALIGNER_F_STREAM_PATH) with the batches in flight, ordinary in the "
                                        "serial figure" if stream_path else "ordinary"),
+                       "dense_path": {"batches_in_flight": args.path_mode, "serial": args.serial_path_mode,
+                                      "note": "fused = aligner_maxpath: one launch, zero workgroups on the idle CUs beside the search, "
+                                              "the utterances' workgroups write the ones; inline = zeros on a second graph branch beside the similarity kernel, the search "
+                                              "kernel writes the ones (ALIGNER_F_PATH_PREZEROED); branch = zeros beside the "
+                                              "search, then a scatter kernel; expand = one kernel behind the search"},
                        "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
                                                                f"{ge} steps" if n > 1 else "")},
             "roofline": roofline,

@@ -83,6 +83,18 @@ extern "C" {
                                       aligner_maxpath_host_f32 does and fails with ALIGNER_EHIP) */
 #define ALIGNER_F_TWO_CUS      512 /* take the two-workgroup form whenever the text has 253..504 rows, whatever
                                       the batch size and mel length (testing; a short sweep loses by it) */
+#define ALIGNER_F_PATH_PREZEROED 2048 /* aligner_maxpath*: path_out_dev already holds zeros (aligner_maxpath_zero_path, on another
+                                      stream or graph branch, BEFORE this call starts): the search kernel writes the
+                                      path's ones itself -- core.pyx:33 on the np.zeros of __init__.py:15 -- and no
+                                      expand kernel follows.  The dense path costs the step's serial chain nothing
+                                      (bench.py, one batch at a time: 65.9 -> see DESIGN 5).  A path that is NOT all
+                                      zero keeps its stale ones: the caller's contract                        */
+#define ALIGNER_F_SEPARATE_EXPAND 4096 /* aligner_maxpath*: always write the dense path with the expand kernel behind the search.
+                                      By default, where the batch leaves at least 32 CUs idle and the one-workgroup-
+                                      per-utterance kernel runs, the search launch carries extra workgroups that write
+                                      the path's zeros on those CUs while the others search, and every utterance's
+                                      workgroup writes its ones at the end: one launch, nothing of the 4*B*Tx*Ty-byte
+                                      write left on the serial chain (same bits; A/B switch for measurements)  */
 #define ALIGNER_F_TEST_DROP_FIRST_HALF 1024 /* testing: in the two-workgroup form the first half of every utterance leaves
                                       without delivering, so the second gives up after its bounded wait: all-zero
                                       path, zero durations, ALIGNER_ST_INTERNAL -- the defined failure of that form */
@@ -179,6 +191,15 @@ int aligner_maxpath_expand(const void *workspace_dev, void *path_out_dev, int pa
                            int B, int Tx, int Ty, void *stream);
 int aligner_maxpath_expand_ex(const void *workspace_dev, void *path_out_dev, int path_dtype,
                            int B, int Tx, int Ty, int flags /* ALIGNER_F_STREAM_PATH */, void *stream);
+
+/* The dense path in the reference's own two steps -- zeros (__init__.py:15), then one 1 per frame (core.pyx:33) -- for
+ * callers with a second stream or a graph branch: aligner_maxpath_zero_path does not depend on the search and can
+ * run BESIDE aligner_maxpath_forward*; aligner_maxpath_scatter_path (after both) then writes t_y elements per
+ * utterance instead of the whole tensor.  Together they equal aligner_maxpath_expand, bit for bit, for every path
+ * dtype; flags: ALIGNER_F_STREAM_PATH (non-temporal zeros).  bench.py's one-batch-at-a-time step is built this way. */
+int aligner_maxpath_zero_path(void *path_out_dev, int path_dtype, int B, int Tx, int Ty, int flags, void *stream);
+int aligner_maxpath_scatter_path(const void *workspace_dev, void *path_out_dev, int path_dtype,
+                                 int B, int Tx, int Ty, void *stream);
 
 /* Blocking read-and-clear of the workspace's status word (ALIGNER_ST_* bits).  The
  * word is sticky: kernels only OR bits into it, so the first 256 bytes of a fresh

@@ -52,7 +52,8 @@ SHAPES = [(1, 1, 1), (3, 7, 13), (2, 63, 64), (4, 64, 257), (2, 127, 1000), (3, 
 
 
 @pytest.mark.parametrize("B,Tx,Ty", SHAPES)
-@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE, _lib.F_STREAM_PATH, _lib.F_TWO_CUS])
+@pytest.mark.parametrize("flags", [0, _lib.F_FORCE_GENERIC, _lib.F_NO_PREV_TABLE, _lib.F_STREAM_PATH, _lib.F_TWO_CUS,
+                                   _lib.F_SEPARATE_EXPAND])
 def test_alignment_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, flags):
     lib = _lib.load()
     rng = np.random.default_rng(B * 1000 + Tx + Ty)
@@ -76,6 +77,53 @@ def test_alignment_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, flags
     O.maximum_path_c(want, value.cpu().numpy().copy(), tx, ty, -1e9)
     assert np.array_equal(path.view(torch.int32, (B, Tx, Ty)).cpu().numpy(), want)
     assert np.array_equal(dur.view(torch.int32, (B, Tx)).cpu().numpy(), want.sum(2))
+
+
+DT_TORCH = {_lib.DT_F32: torch.float32, _lib.DT_F16: torch.float16, _lib.DT_BF16: torch.bfloat16, _lib.DT_F64: torch.float64,
+            _lib.DT_I32: torch.int32, _lib.DT_U8: torch.uint8, _lib.DT_I64: torch.int64}
+
+
+@pytest.mark.parametrize("B,Tx,Ty", [(1, 1, 1), (3, 7, 13), (2, 63, 65), (3, 200, 1001), (2, 330, 704)])
+@pytest.mark.parametrize("pdt", list(DT_TORCH))
+@pytest.mark.parametrize("misalign", [0, 2])
+def test_zero_and_scatter_writes_stay_inside_their_buffers(dev, B, Tx, Ty, pdt, misalign):
+    """The dense path in two steps (zeros beside the search, then one 1 per frame): every dtype, odd sizes, and a path
+    pointer that is not 16-byte aligned (the zero kernel's byte-wise head and tail); equal to expand, inside the fence."""
+    lib = _lib.load()
+    es = torch.empty((), dtype=DT_TORCH[pdt]).element_size()
+    off = misalign * es
+    rng = np.random.default_rng(B + Tx + Ty)
+    value = torch.from_numpy(synth.synth_value(B, Tx, Ty, seed=Tx * Ty)).to(dev)
+    ty = rng.integers(max(1, Ty // 2), Ty + 1, B).astype(np.int32)
+    tx = np.array([rng.integers(1, min(Tx, t) + 1) for t in ty], np.int32)
+    tx[0], ty[0] = min(Tx, Ty), Ty
+    d_tx, d_ty = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    wsb = lib.aligner_maxpath_workspace_bytes(B, Tx, Ty)
+    ws = Fenced(wsb, dev)
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.aligner_maxpath_forward_f32(value.data_ptr(), None, 0, d_tx.data_ptr(), d_ty.data_ptr(), None, None, ws.ptr,
+                                               wsb, B, Tx, Ty, -1e9, 0, s))
+    n = B * Tx * Ty * es
+    two = Fenced(n + off, dev)
+    two.buf[two.lo:two.hi] = 0x77                                  # stale contents the zeros must overwrite
+    two.buf[two.lo:two.lo + off] = CANARY                          # (the bytes before a misaligned path are fence too)
+    for fl in (0, _lib.F_STREAM_PATH):
+        _lib.check(lib.aligner_maxpath_zero_path(two.ptr + off, pdt, B, Tx, Ty, fl, s))
+        _lib.check(lib.aligner_maxpath_scatter_path(ws.ptr, two.ptr + off, pdt, B, Tx, Ty, s))
+        torch.cuda.synchronize()
+        assert two.intact() and bool((two.buf[two.lo:two.lo + off] == CANARY).all()), "zero/scatter wrote outside the path"
+        got = two.buf[two.lo + off:two.hi].clone().view(DT_TORCH[pdt]).reshape(B, Tx, Ty)
+        if off == 0:
+            one = Fenced(n, dev)
+            _lib.check(lib.aligner_maxpath_expand(ws.ptr, one.ptr, pdt, B, Tx, Ty, s))
+            torch.cuda.synchronize()
+            assert torch.equal(got.view(torch.uint8), one.view(DT_TORCH[pdt], (B, Tx, Ty)).view(torch.uint8))
+        from oracle import maxpath_oracle as O
+        want = np.zeros((B, Tx, Ty), np.int32)
+        O.maximum_path_c(want, value.cpu().numpy().copy(), tx, ty, -1e9)
+        assert np.array_equal(got.to(torch.int32).cpu().numpy(), want)
+        two.buf[two.lo + off:two.hi] = 0x77
+    assert ws.intact()
 
 
 @pytest.mark.parametrize("B,C,Tx,Ty", [(2, 80, 50, 130), (3, 80, 200, 1000), (1, 16, 33, 65), (2, 80, 257, 300),

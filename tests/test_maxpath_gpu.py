@@ -46,7 +46,7 @@ def _check_consistency(path, tok, dur, tx, ty):
 
 
 KERNELS = {"wide": {}, "wide_retry_walk": {"no_prev_table": True}, "generic": {"force_generic": True},
-           "wide_streamed_path": {"stream_path": True}}
+           "wide_streamed_path": {"stream_path": True}, "wide_separate_expand": {"_test_flags": 4096}}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -418,6 +418,12 @@ def test_expand_dtypes(dev, dt):
     r = aligner_amd.align(torch.from_numpy(v4).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty4).to(dev),
                           path_dtype=dt, stream_path=True)
     assert r.path.dtype == dt and np.array_equal(r.path.to(torch.int32).cpu().numpy(), _oracle_path(v4, tx, ty4))
+    # the caller's zeros + the search kernel's own ones (ALIGNER_F_PATH_PREZEROED), every kernel form
+    for kw in ({}, {"force_generic": True}, {"no_prev_table": True}):
+        out = torch.zeros((3, 17, 52), dtype=dt, device=dev)
+        r = aligner_amd.align(torch.from_numpy(v4).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty4).to(dev),
+                              out_path=out, out_path_is_zero=True, **kw)
+        assert r.path is out and np.array_equal(out.to(torch.int32).cpu().numpy(), _oracle_path(v4, tx, ty4)), kw
     # odd Ty exercises the unaligned (scalar) load/store paths
     v = synth.synth_value(2, 9, 37, 5)
     r = aligner_amd.align(torch.from_numpy(v).to(dev), torch.tensor([9, 3], dtype=torch.int32, device=dev),
@@ -526,6 +532,19 @@ def test_two_workgroups_per_utterance(dev):
         res = aligner_amd.align(torch.from_numpy(v).to(dev), mask=torch.from_numpy(mask).to(dev), strict_mask=True,
                                 path_dtype=torch.int32, cus_per_utterance=cus)
         assert np.array_equal(res.path.cpu().numpy(), want), cus
+
+
+def test_prezeroed_path_at_the_baseline_shapes(appendix_a, dev):
+    """ALIGNER_F_PATH_PREZEROED at C2 (ragged), a C4 shard and C5 (two workgroups per utterance): the reference's hashes."""
+    import aligner_amd
+    rec, _ = appendix_a
+    for tag in ("C2-varlen", "C4-shard0", "C5-longform"):
+        v, tx, ty = _config(tag)
+        out = torch.zeros(v.shape, dtype=torch.int32, device=dev)
+        aligner_amd.align(torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev),
+                          out_path=out, out_path_is_zero=True)
+        assert synth.sha256_of(out.cpu().numpy()) == rec[tag]["path_sha256"], tag
+    assert aligner_amd.read_status(dev) == 0
 
 
 def test_two_workgroups_full_size_long_form(appendix_a, dev):
