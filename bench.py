@@ -396,6 +396,199 @@ def run_c4(args, world: int, rank: int, local: int):
         dist.destroy_process_group()
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 matrix peak (not the 2:1-sparsity headline)
+
+
+def _single_gpu_only(world: int, name: str):
+    if world != 1:
+        raise SystemExit(f"--config {name} is a one-GPU line (BASELINE names it for one MI355X); run it with --gpus 1")
+
+
+def _timed_region(step, nsteps: int, dev) -> float:
+    """EXACTLY nsteps steps bracketed by synchronize on both sides (one rank: no barrier partner)."""
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize(dev)
+    return time.perf_counter() - t0
+
+
+def _cpu_dp_baseline(value: np.ndarray, tx: np.ndarray, ty: np.ndarray, what: str, seconds: float = 8.0):
+    """The reference's maximum_path_c (its pinned C restatement, one thread: the reference ships serial) on this config's
+    score shape -- the part of the config the reference snapshot contains."""
+    from oracle import maxpath_oracle as O
+    paths = np.zeros(value.shape, np.int32)
+    work = value.copy()
+    O.maximum_path_c(paths, work, tx, ty)
+    reps, spent = 0, 0.0
+    while spent < seconds and reps < 500:
+        np.copyto(work, value)
+        paths.fill(0)
+        t0 = time.perf_counter()
+        O.maximum_path_c(paths, work, tx, ty)
+        spent += time.perf_counter() - t0
+        reps += 1
+    nb = value.shape[0]
+    return {"value": round(nb * reps / spent, 1), "unit": "utterances/s", "cores": 1, "kind": "port",
+            "sample": f"maximum_path_c core (C restatement, oracle/maxpath_oracle.c) on {what}: {reps} batches in "
+                      f"{spent:.1f}s ({spent / reps * 1e3:.1f} ms/batch); the conv / similarity / boundary-search stages "
+                      f"have no counterpart in the reference snapshot", "host_logical_cores": os.cpu_count()}
+
+
+def run_c3(args, world: int):
+    """BASELINE configs[2]: the full OTA pipeline on an LJSpeech-shaped batch -- conv text / mel encoders -> similarity +
+    log-softmax -> alignment search with dense path and durations; [64, 512-dim text embedding x 200, 80-mel x 900]."""
+    _single_gpu_only(world, "c3")
+    import aligner_amd
+    _lib.require_gpu()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    Bc, Ct, Cm, Ca, Tx, Ty = 64, 512, 80, 80, 200, 900
+    g = torch.Generator().manual_seed(33)
+    params = aligner_amd.AlignmentEncoderParams.random(Ct, Cm, Ca, dev, seed=3)
+    text = torch.randn(Bc, Ct, Tx, generator=g).to(dev)
+    mel = torch.randn(Bc, Cm, Ty, generator=g).to(dev)
+    tx = torch.full((Bc,), Tx, dtype=torch.int32, device=dev)
+    ty = torch.full((Bc,), Ty, dtype=torch.int32, device=dev)
+    out = {}
+
+    def step():
+        logp, _ = aligner_amd.alignment_encoder(text, mel, params, t_x=tx)
+        out["logp"] = logp
+        out["res"] = aligner_amd.align(logp, tx, ty, want_tok=True)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    elapsed = _timed_region(step, args.steps, dev)
+    res, logp = out["res"], out["logp"]
+    # guards on the timed outputs: every log-prob column is a distribution over the text, the path is one token per
+    # frame, monotone, and its row sums are the durations
+    col = torch.logsumexp(logp, dim=1)
+    assert float(col.abs().max()) < 1e-3, "log-softmax columns do not sum to 1"
+    assert int(res.durations.sum()) == Bc * Ty and bool((res.path.sum(1) == 1).all())
+    assert bool((res.path.sum(2).to(torch.int32) == res.durations).all())
+    assert bool((res.tok[:, 1:] - res.tok[:, :-1] >= 0).all()) and bool((res.tok[:, 1:] - res.tok[:, :-1] <= 1).all())
+    # stage timings (HIP events on the launch stream, second pass over the same buffers)
+    k1 = aligner_amd.softattn.conv1d(text, *params.key_proj[0], relu=True)
+    k = aligner_amd.softattn.encode(text, params.key_proj)
+    q = aligner_amd.softattn.encode(mel, params.query_proj)
+    it = 20
+    stages = {
+        "text encoder conv 512->1024 k3 (conv1d_prepared_kernel)": (event_time_us(lambda: aligner_amd.softattn.conv1d(text, *params.key_proj[0], relu=True), it, dev), 2.0 * Bc * Tx * Ct * 2 * Ct * 3),
+        "text encoder conv 1024->80 k1": (event_time_us(lambda: aligner_amd.softattn.conv1d(k1, *params.key_proj[1]), it, dev), 2.0 * Bc * Tx * 2 * Ct * Ca),
+        "mel encoder (3 convs)": (event_time_us(lambda: aligner_amd.softattn.encode(mel, params.query_proj), it, dev), 2.0 * Bc * Ty * (Cm * 2 * Cm * 3 + 2 * Cm * Cm + Cm * Ca)),
+        "similarity + log-softmax (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx), it, dev), 2.0 * Bc * Tx * Ty * Ca),
+        "alignment search + dense path (maxpath_pipelined_kernel)": (event_time_us(lambda: aligner_amd.align(logp, tx, ty), it, dev), 0.0),
+    }
+    dom = max(stages, key=lambda n: stages[n][0])
+    tfl = stages[dom][1] / (stages[dom][0] * 1e-6) / 1e12
+    ups = Bc * args.steps / elapsed
+    line = {
+        "metric": "aligned utterances/sec, full OTA pipeline (conv encoders -> similarity -> alignment search), "
+                  "[B=64, 512-dim text x 200, 80-mel x 900]",
+        "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * Ty, 1), "n_gpus": 1,
+        "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: conv text encoder (512->1024 k3, ReLU, 1024->80 k1) + conv mel encoder (80->160 k3, "
+                               "160->80, 80->80) + similarity (L2, C=80) + log-softmax + monotonic alignment search with dense "
+                               "fp32 path and int32 durations; [64, 512x200 text embedding, 80x900 mel], eager launches",
+                   "batch_per_gpu": Bc, "t_text": Tx, "t_mel": Ty},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(tfl, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tfl / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel_us": round(stages[dom][0], 2),
+                     "algorithmic_flops": stages[dom][1],
+                     "note": "algorithmic flops of the fp32 convolution; the kernel issues three bf16 MFMAs per product "
+                             "(hi*hi + hi*lo + lo*hi of the split operands), i.e. 3x these flops on the matrix cores",
+                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()}},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = _cpu_dp_baseline(logp.cpu().numpy(), np.full(Bc, Tx, np.int32), np.full(Bc, Ty, np.int32),
+                                                "this step's own [64,200,900] log-probs")
+    print(json.dumps(line), flush=True)
+
+
+def run_c5(args, world: int):
+    """BASELINE configs[4]: long-form [T_text=500, T_mel=4000] -- bf16 similarity, the alignment search on the bf16
+    log-probs with an int32 path, and the MoBoAligner boundary search on the same energies."""
+    _single_gpu_only(world, "c5")
+    import hashlib
+    import aligner_amd
+    from aligner_amd import mobo
+    _lib.require_gpu()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    Bc, Ca, Tx, Ty, D = 8, 80, 500, 4000, args.max_duration
+    g = torch.Generator().manual_seed(55)
+    kk = torch.randn(Bc, Ca, Tx, generator=g).to(dev)
+    qq = torch.randn(Bc, Ca, Ty, generator=g).to(dev)
+    tx = torch.full((Bc,), Tx, dtype=torch.int32, device=dev)
+    ty = torch.full((Bc,), Ty, dtype=torch.int32, device=dev)
+    out = {}
+
+    def step():
+        lp, _ = aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16)
+        out["lp"] = lp
+        out["res"] = aligner_amd.align(lp, tx, ty, path_dtype=torch.int32)
+        out["bs"] = aligner_amd.boundary_search(lp, tx, ty, D)
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    elapsed = _timed_region(step, args.steps, dev)
+    lp, res, bs = out["lp"], out["res"], out["bs"]
+    assert aligner_amd.read_status(dev) == 0 and mobo.read_status(dev) == 0
+    # guards on the timed outputs
+    assert int(res.durations.sum()) == Bc * Ty and bool((res.path.sum(1) == 1).all())
+    dur = bs.durations
+    assert bool((dur >= 1).all()) and bool((dur <= D).all()) and bool((dur.sum(1) == Ty).all())
+    assert bool((bs.boundaries[:, -1] == Ty).all()) and bool(torch.isfinite(bs.map_score).all())
+    # and the alignment search on the configuration's own synthetic scores: the reference's hash (SURVEY Appendix A)
+    ref_ok = None
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "appendix_a.json")) as f:
+            rec = json.load(f)
+        v = torch.from_numpy(synth.synth_value(Bc, Tx, Ty, 5, bits=8, denom=8.0)).to(dev).to(torch.bfloat16)
+        r5 = aligner_amd.align(v, tx, ty, path_dtype=torch.int32)
+        ref_ok = hashlib.sha256(np.ascontiguousarray(r5.path.cpu().numpy().astype(np.int32)).tobytes()).hexdigest() == \
+            rec["C5-longform"]["path_sha256"]
+    except (OSError, KeyError, ValueError):
+        ref_ok = None
+    assert ref_ok is not False, "C5 path differs from the reference's hash"
+    it = 10
+    cells = Bc * Tx * Ty
+    stages = {
+        "similarity, bf16 log-probs (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16), it, dev), 4 * Bc * Ca * (Tx + Ty) + 2 * cells),
+        "alignment search on bf16 + int32 dense path (maxpath_pipelined_kernel x2 CUs + expand)": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, path_dtype=torch.int32), it, dev), 2 * cells + 4 * cells),
+        "alignment search, durations only": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, want_path=False), it, dev), 2 * cells),
+        f"boundary search, max duration {D} (norm + chain + backtrack kernels)": (event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D), it, dev), 2 * cells + 4 * cells + 2 * cells + 4 * cells + 2 * cells),
+    }
+    dom = max(stages, key=lambda n: stages[n][0])
+    gbs = stages[dom][1] / (stages[dom][0] * 1e-6) / 1e9
+    ups = Bc * args.steps / elapsed
+    line = {
+        "metric": "aligned utterances/sec, long-form [B=8, T_text=500, T_mel=4000]: bf16 similarity + alignment search (int32 "
+                  "path) + MoBoAligner boundary search",
+        "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * Ty, 1), "n_gpus": 1,
+        "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 scores, f32 arithmetic, i32 path",
+        "data": "synthetic",
+        "config": {"workload": f"configs[4]: similarity (L2, C=80) with bf16 log-probs -> maximum_path on them (dense int32 path + "
+                               f"durations) -> boundary search with max duration {D} on the same energies; [8,500,4000], eager launches",
+                   "batch_per_gpu": Bc, "t_text": Tx, "t_mel": Ty, "max_duration": D},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel_us": round(stages[dom][0], 2),
+                     "algorithmic_bytes": stages[dom][1],
+                     "note": "boundary search bytes: energies read twice (2+2 B/cell: normalisers, chain), normalisers written and "
+                             "read (4+4), durations written (2); it is bound by the dependent chain over the 500 token rows "
+                             "(DESIGN 7.1), not by memory",
+                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()}},
+        "alignment_path_matches_reference_hash_on_C5_scores": ref_ok,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = _cpu_dp_baseline(synth.synth_value(Bc, Tx, Ty, 5, bits=8, denom=8.0), np.full(Bc, Tx, np.int32),
+                                                np.full(Bc, Ty, np.int32), "the [8,500,4000] scores of SURVEY Appendix A")
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,13 +612,19 @@ def main():
                          "(ALIGNER_F_PATH_PREZEROED)")
     ap.add_argument("--streams", type=int, default=3,
                     help="independent batches in flight (one HIP stream + buffer set each); 1 = strictly serial steps")
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
-                    help="c2 (default): BASELINE configs[1], the headline; c4: configs[3], the 512-utterance ragged job")
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2",
+                    help="c2 (default): BASELINE configs[1], the headline; c3: configs[2], the full OTA pipeline; c4: configs[3], "
+                         "the 512-utterance ragged job; c5: configs[4], long-form bf16 similarity + alignment + boundary search")
+    ap.add_argument("--max-duration", type=int, default=32, help="c5: the boundary search's maximum-duration window")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.config in ("c3", "c5"):
+        if args.steps == 200 and args.warmup == 20:
+            args.steps, args.warmup = 30, 5              # a step is 0.4-1.5 ms of several launches
+        return run_c3(args, world) if args.config == "c3" else run_c5(args, world)
     if args.config == "c4":
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
