@@ -72,6 +72,8 @@ SIGNATURES = {
     "aligner_conv1d_prepared_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aligner_forward_sum_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_forward_sum_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "aligner_forward_sum_ctc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "aligner_forward_sum_ctc_f32": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_beta_binomial_prior_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "aligner_boundary_search_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_boundary_search_workspace_bytes_ex": (_sz, [_i, _i, _i, _i]),

@@ -648,6 +648,304 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
     }
 }
 
+// --------------------------------------------------------------------------
+// The CTC form of the objective (the published one: OTA's ForwardSumLoss, README.md:21-25,50 -- a blank column
+// at log-prob `blank` is put before the text, every frame is renormalised over blank + text (log_softmax), and
+// the loss is the CTC loss of the token sequence 1..t_x): between two tokens, before the first and after the
+// last a frame may be "blank".  States per token row r: B_r (blank before token r) and T_r (token r); row t_x
+// holds the blank after the last token.
+//     B_r(y) = blank  + lse( B_r(y-1), T_{r-1}(y-1) )
+//     T_r(y) = x[r,y] + lse( T_r(y-1), B_r(y-1), T_{r-1}(y-1) )          start: B_0(-1) = log 1
+//     Z = T_{tx-1}(ty-1) + B_tx(ty-1)
+// The per-frame log_softmax normaliser n_y = lse(blank, x[.,y]) multiplies every path by the same factor, so the
+// sweeps run on the raw scores and  loss = -(log Z - sum_y n_y);  d loss / d x[r,y] = softmax_y(r) - occupancy of
+// T_r at y.  n_y comes from a row-parallel kernel of its own (ctc_colnorm_kernel).  Same one-sweeping-wave design
+// and numerics (base-2 logs, FS_NEG, drift / re-basing into double offsets) as the kernels above; pinned to
+// torch.nn.functional.ctc_loss in float64 (tests/test_objective.py) -- the one externally pinned row of 8f.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ float fs_lae3(float a, float b, float c) {
+    const float m = fmaxf(fmaxf(a, b), c);
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) +
+                                     __builtin_amdgcn_exp2f(c - m));
+}
+
+struct CtcParams {
+    FwdSumParams f;         // logp = the raw scores x; alpha = log2 alpha of the TOKEN states
+    float *nrm;             // workspace [B,Ty]: n_y, base 2
+    float blank2;           // blank score, base 2
+};
+
+// n_y = log2( 2^blank + sum_{r < t_x} 2^x[r,y] ): one thread per frame, rows streamed (coalesced over frames)
+__global__ __launch_bounds__(256) void ctc_colnorm_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    const int b = blockIdx.y, y = blockIdx.x * 256 + threadIdx.x;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    if (y >= p.Ty) return;
+    float m = q.blank2, s = 1.f;
+    if (y < ty) {
+        const float *col = p.logp + (size_t)b * p.Tx * p.Ty + y;
+        for (int r = 0; r < tx; ++r) {
+            const float v = fs_in(col[(size_t)r * p.Ty]);
+            const float mn = fmaxf(m, v);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(v - mn);
+            m = mn;
+        }
+    }
+    q.nrm[(size_t)b * p.Ty + y] = m + __builtin_amdgcn_logf(s);
+}
+
+template <int R>
+__global__ __launch_bounds__(FS_THREADS) void fwdsum_ctc_forward_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    constexpr int TW = 128 / R, ROWS = 64 * R + 4;
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tin = fs_smem;                         // [2][TW][ROWS] scores, frame-major
+    float *tout = tin + 2 * TW * ROWS;            // [2][TW][ROWS] alpha of the token states
+    double *toff = reinterpret_cast<double *>(tout + 2 * TW * ROWS);   // [2][TW]
+    float *tnrm = reinterpret_cast<float *>(toff + 2 * TW);            // [2][TW] n_y
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const bool sweeper = tid < 64;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    if (!(tx >= 1 && tx <= ty)) {                 // fewer frames than tokens: no labelling exists, loss = +inf
+        if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
+        for (int t = tid; t < p.NT; t += FS_THREADS) p.offs[(size_t)b * p.NT + t] = 0.0;
+        return;
+    }
+    const int ntl = (ty + TW - 1) / TW;
+    float pB[R], pT[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { pB[j] = FS_NEG; pT[j] = FS_NEG; }
+    if (lane == 0) pB[0] = 0.f;                   // B_0 before the first frame: log 1
+    float drift = 0.f;
+    double C = 0.0, NS = 0.0;                     // NS: sum of the frames' normalisers
+    for (int ph = 0; ph < ntl + 2; ++ph) {
+        if (!sweeper) {
+            const int s = tid - 64;
+            if (ph < ntl) {
+                float *dst = tin + (ph & 1) * TW * ROWS;
+                const int y0 = ph * TW;
+                constexpr int NEL = TW * 64 * R, NIT = (NEL + FS_STAGERS - 1) / FS_STAGERS;
+                float v[NIT];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    int e = s + i * FS_STAGERS;
+                    e = e < NEL ? e : NEL - 1;
+                    const int r = e / TW, c = e - r * TW;
+                    const int rc = r < tx ? r : tx - 1, yc = y0 + c < ty ? y0 + c : ty - 1;
+                    v[i] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+                }
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int e = s + i * FS_STAGERS;
+                    if (e < NEL) { const int r = e / TW, c = e - r * TW; dst[c * ROWS + r] = fs_in(v[i]); }
+                }
+                if (s < TW) tnrm[(ph & 1) * TW + s] = (y0 + s < ty) ? q.nrm[(size_t)b * p.Ty + y0 + s] : 0.f;
+            }
+            if (ph >= 2) {
+                const float *src = tout + (ph & 1) * TW * ROWS;
+                const int y0 = (ph - 2) * TW;
+                for (int e = s; e < TW * 64 * R; e += FS_STAGERS) {
+                    const int r = e / TW, c = e - r * TW;
+                    if (r < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)r * p.Ty + y0 + c] = src[c * ROWS + r];
+                }
+                if (s < TW && y0 + s < ty) p.offs[(size_t)b * p.NT + y0 + s] = toff[(ph & 1) * TW + s];
+            }
+        } else if (ph >= 1 && ph <= ntl) {
+            const int t = ph - 1, y0 = t * TW;
+            const float *src = tin + (t & 1) * TW * ROWS + R * lane;
+            float *dst = tout + (t & 1) * TW * ROWS + R * lane;
+            for (int c = 0; c < TW; ++c) {
+                const int y = y0 + c;
+                if (y >= ty) break;                                                  // uniform: padding frames
+                float x[R];
+#pragma unroll
+                for (int j = 0; j < R; j += 4) {
+                    const float4 w = *reinterpret_cast<const float4 *>(src + c * ROWS + j);
+                    x[j] = w.x; x[j + 1] = w.y; x[j + 2] = w.z; x[j + 3] = w.w;
+                }
+                NS += (double)tnrm[(t & 1) * TW + c];
+                const float up0 = fs_from_lane_below(FS_NEG, pT[R - 1]);             // T of the row below this lane's first
+                const float bl = q.blank2 - drift;
+                float nB[R], nT[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int row = R * lane + j;
+                    const float upT = j ? pT[j - 1] : up0;
+                    const float vb = fs_lae2(pB[j], upT) + bl;
+                    const float vt = fs_lae3(pT[j], pB[j], upT) + (x[j] - drift);
+                    nB[j] = (row <= tx) ? fmaxf(vb, FS_NEG) : FS_NEG;
+                    nT[j] = (row < tx) ? fmaxf(vt, FS_NEG) : FS_NEG;
+                }
+                C += (double)drift;
+                if (lane == 0) toff[(t & 1) * TW + c] = C;
+#pragma unroll
+                for (int j = 0; j < R; j += 4)
+                    *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(nT[j], nT[j + 1], nT[j + 2], nT[j + 3]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) { pB[j] = nB[j]; pT[j] = nT[j]; }
+                if (y == ty - 1) {                                                  // uniform: Z = T_{tx-1} + B_tx
+                    const float upn = fs_from_lane_below(FS_NEG, pT[R - 1]);
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+                        if (R * lane + j == tx) {
+                            const double lz = (double)fs_lae2(pB[j], j ? pT[j - 1] : upn) + C;     // log2 Z of the raw scores
+                            p.logz[b] = lz;
+                            p.loss[b] = (float)(-(lz - NS) * FS_LN2);
+                        }
+                }
+                if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                    float m = fmaxf(pB[0], pT[0]);
+#pragma unroll
+                    for (int j = 1; j < R; ++j) m = fmaxf(m, fmaxf(pB[j], pT[j]));
+                    m = fs_wave_max_dpp(m);
+                    if (m < 0.5f * FS_NEG) m = 0.f;
+                    C += (double)m;
+                    drift += m * (1.0f / FS_RB);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { pB[j] = fmaxf(pB[j] - m, FS_NEG); pT[j] = fmaxf(pT[j] - m, FS_NEG); }
+                }
+            }
+        }
+        fs_lds_barrier();
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(FS_THREADS) void fwdsum_ctc_backward_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    constexpr int TW = 64 / R, ROWS = 64 * R + 4;
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tlp = fs_smem;                         // [2][TW][ROWS] scores
+    float *tal = tlp + 2 * TW * ROWS;             // [2][TW][ROWS] alpha of the token states (relative to C_y)
+    float *tgr = tal + 2 * TW * ROWS;             // [2][TW][ROWS] gradient out
+    double *toff = reinterpret_cast<double *>(tgr + 2 * TW * ROWS);    // [2][TW] C_y
+    float *tnrm = reinterpret_cast<float *>(toff + 2 * TW);            // [2][TW] n_y
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const bool sweeper = tid < 64;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int ntl = ok ? (ty + TW - 1) / TW : 0;
+    for (int r = 0; r < p.Tx; ++r)
+        for (int y = ntl * TW + tid; y < p.Ty; y += FS_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
+    if (!ok) return;
+    const double logz = p.logz[b];
+    float gB[R], gT[R];                           // beta + emission of frame y+1, relative to D
+#pragma unroll
+    for (int j = 0; j < R; ++j) { gB[j] = FS_NEG; gT[j] = FS_NEG; }
+    float drift = 0.f;
+    double D = 0.0;
+    for (int ph = 0; ph < ntl + 2; ++ph) {
+        if (!sweeper) {
+            const int s = tid - 64;
+            if (ph < ntl) {
+                const int t = ntl - 1 - ph, y0 = t * TW;
+                float *dlp = tlp + (ph & 1) * TW * ROWS, *dal = tal + (ph & 1) * TW * ROWS;
+                constexpr int NEL = TW * 64 * R, NIT = (NEL + FS_STAGERS - 1) / FS_STAGERS;
+                float v[NIT], w[NIT];
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    int e = s + i * FS_STAGERS;
+                    e = e < NEL ? e : NEL - 1;
+                    const int r = e / TW, c = e - r * TW;
+                    const int rc = r < tx ? r : tx - 1, yc = y0 + c < ty ? y0 + c : ty - 1;
+                    v[i] = p.logp[ubase + (size_t)rc * p.Ty + yc];
+                    w[i] = p.alpha[ubase + (size_t)rc * p.Ty + yc];
+                }
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    const int e = s + i * FS_STAGERS;
+                    if (e < NEL) {
+                        const int r = e / TW, c = e - r * TW;
+                        dlp[c * ROWS + r] = fs_in(v[i]);
+                        dal[c * ROWS + r] = w[i];
+                    }
+                }
+                if (s < TW) {
+                    toff[(ph & 1) * TW + s] = (y0 + s < ty) ? p.offs[(size_t)b * p.NT + y0 + s] : 0.0;
+                    tnrm[(ph & 1) * TW + s] = (y0 + s < ty) ? q.nrm[(size_t)b * p.Ty + y0 + s] : 0.f;
+                }
+            }
+            if (ph >= 2) {
+                const float *src = tgr + (ph & 1) * TW * ROWS;
+                const int y0 = (ntl - 1 - (ph - 2)) * TW;
+                for (int e = s; e < TW * 64 * R; e += FS_STAGERS) {
+                    const int r = e / TW, c = e - r * TW;
+                    if (r < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)r * p.Ty + y0 + c] = src[c * ROWS + r];
+                }
+            }
+        } else if (ph >= 1 && ph <= ntl) {
+            const int buf = (ph - 1) & 1, y0 = (ntl - 1 - (ph - 1)) * TW;
+            const float *slp = tlp + buf * TW * ROWS + R * lane, *sal = tal + buf * TW * ROWS + R * lane;
+            float *dst = tgr + buf * TW * ROWS + R * lane;
+            for (int c = TW - 1; c >= 0; --c) {
+                const int y = y0 + c;
+                if (y >= ty) {                                                       // uniform: padding frames
+#pragma unroll
+                    for (int j = 0; j < R; j += 4) *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
+                float x[R], al[R];
+#pragma unroll
+                for (int j = 0; j < R; j += 4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(slp + c * ROWS + j);
+                    const float4 w = *reinterpret_cast<const float4 *>(sal + c * ROWS + j);
+                    x[j] = v.x; x[j + 1] = v.y; x[j + 2] = v.z; x[j + 3] = v.w;
+                    al[j] = w.x; al[j + 1] = w.y; al[j + 2] = w.z; al[j + 3] = w.w;
+                }
+                const float st = (float)(toff[buf * TW + c] + D - logz);            // uniform
+                const float ny = tnrm[buf * TW + c];
+                const float aB = fs_from_lane_above(FS_NEG, gB[0]);                  // row above this lane's last one
+                const float aT = fs_from_lane_above(FS_NEG, gT[0]);
+                float nB[R], nT[R], gr[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int row = R * lane + j;
+                    float bT, bB;
+                    if (y == ty - 1) {                                               // uniform branch
+                        bT = (row == tx - 1) ? 0.f : FS_NEG;
+                        bB = (row == tx) ? 0.f : FS_NEG;
+                    } else {
+                        bT = fs_lae3(gT[j], j + 1 < R ? gB[j + 1] : aB, j + 1 < R ? gT[j + 1] : aT);
+                        bB = fs_lae2(gB[j], gT[j]);
+                    }
+                    if (row >= tx) bT = FS_NEG;
+                    if (row > tx) bB = FS_NEG;
+                    const float occ = __builtin_amdgcn_exp2f(al[j] + bT + st);       // 2^(-1e30) = 0
+                    gr[j] = (row < tx) ? __builtin_amdgcn_exp2f(x[j] - ny) - occ : 0.f;
+                    nT[j] = fmaxf(bT + (x[j] - drift), FS_NEG);
+                    nB[j] = fmaxf(bB + (q.blank2 - drift), FS_NEG);
+                }
+                D += (double)drift;
+#pragma unroll
+                for (int j = 0; j < R; j += 4)
+                    *reinterpret_cast<float4 *>(dst + c * ROWS + j) = make_float4(gr[j], gr[j + 1], gr[j + 2], gr[j + 3]);
+#pragma unroll
+                for (int j = 0; j < R; ++j) { gB[j] = nB[j]; gT[j] = nT[j]; }
+                if ((c & (FS_RB - 1)) == 0) {
+                    float m = fmaxf(gB[0], gT[0]);
+#pragma unroll
+                    for (int j = 1; j < R; ++j) m = fmaxf(m, fmaxf(gB[j], gT[j]));
+                    m = fs_wave_max_dpp(m);
+                    if (m < 0.5f * FS_NEG) m = 0.f;
+                    D += (double)m;
+                    drift += m * (1.0f / FS_RB);
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { gB[j] = fmaxf(gB[j] - m, FS_NEG); gT[j] = fmaxf(gT[j] - m, FS_NEG); }
+                }
+            }
+        }
+        fs_lds_barrier();
+    }
+}
+
 struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, R; };
 
 static FsLayout fs_layout(int B, int Tx, int Ty) {
@@ -697,6 +995,26 @@ static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
     return ALIGNER_OK;
 }
 
+template <int R>
+static int fs_launch_ctc(const CtcParams &q, bool backward, hipStream_t s) {
+    constexpr int ROWS = 64 * R + 4;
+    const size_t lds_f = (size_t)4 * (128 / R) * ROWS * sizeof(float) + 2 * (128 / R) * (sizeof(double) + sizeof(float));
+    const size_t lds_b = (size_t)6 * (64 / R) * ROWS * sizeof(float) + 2 * (64 / R) * (sizeof(double) + sizeof(float));
+    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 255) / 256, q.f.B), dim3(256), 0, s, q);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    auto kf = fwdsum_ctc_forward_kernel<R>;
+    auto kb = fwdsum_ctc_backward_kernel<R>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
+    hipLaunchKernelGGL(kf, dim3(q.f.B), dim3(FS_THREADS), lds_f, s, q);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    if (backward) {
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
+        hipLaunchKernelGGL(kb, dim3(q.f.B), dim3(FS_THREADS), lds_b, s, q);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    return ALIGNER_OK;
+}
+
 }  // namespace aligner
 
 using namespace aligner;
@@ -730,6 +1048,35 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
     if (L.R == 4) return fs_launch<4>(p, bwd, s);
     if (L.R == 8) return fs_launch<8>(p, bwd, s);
     return fs_launch<16>(p, bwd, s);
+}
+
+size_t aligner_forward_sum_ctc_workspace_bytes(int B, int Tx, int Ty) {
+    if (B < 0 || Tx < 1 || Ty < 1 || Tx > 1023) return 0;
+    return fs_layout(B, Tx, Ty).total + align_up((size_t)B * Ty * sizeof(float), 256);
+}
+
+int aligner_forward_sum_ctc_f32(const float *scores, const int32_t *t_xs, const int32_t *t_ys, float blank_logprob,
+                                float *loss_out, float *grad_out, void *workspace, size_t workspace_bytes, int B, int Tx,
+                                int Ty, void *stream) {
+    if (!scores || !t_xs || !t_ys || !loss_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
+    if (Tx > 1023) return fail(ALIGNER_EDOM, "Tx=%d exceeds 1023 text rows (the blank after the last token takes a row)", Tx);
+    if (!(blank_logprob - blank_logprob == 0.0f)) return fail(ALIGNER_EINVAL, "blank_logprob must be finite");
+    if (B == 0) return ALIGNER_OK;
+    if (B > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    const FsLayout L = fs_layout(B, Tx, Ty);
+    const size_t total = L.total + align_up((size_t)B * Ty * sizeof(float), 256);
+    if (workspace_bytes < total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, total);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    CtcParams q{{scores, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off), reinterpret_cast<double *>(ws + L.offs_off),
+                 reinterpret_cast<double *>(ws + L.logz_off), loss_out, grad_out, B, Tx, Ty, L.NT},
+                reinterpret_cast<float *>(ws + L.total), blank_logprob * FS_LOG2E};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bwd = grad_out != nullptr;
+    // rows 0..t_x: the blank after the last token needs a row of its own
+    if (Tx + 1 <= 256) return fs_launch_ctc<4>(q, bwd, s);
+    if (Tx + 1 <= 512) return fs_launch_ctc<8>(q, bwd, s);
+    return fs_launch_ctc<16>(q, bwd, s);
 }
 
 }  // extern "C"

@@ -30,10 +30,14 @@ def _lengths(t: torch.Tensor, name: str, B: int, dev) -> torch.Tensor:
     return t
 
 
-def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_grad: bool = True
-                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_grad: bool = True,
+                blank_logprob: Optional[float] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """loss[B] = -log sum over monotonic alignments of prod_y exp(logp[b, x(y), y]) and, if
-    `want_grad`, d loss / d logp [B,T_text,T_mel] (= minus the posterior occupancy of each cell)."""
+    `want_grad`, d loss / d logp [B,T_text,T_mel] (= minus the posterior occupancy of each cell).
+
+    blank_logprob (e.g. -1.0): the CTC form the OTA paper's code trains with instead -- a blank column at that
+    log-prob before the text, every frame renormalised over blank + text, loss = CTC loss of the tokens 1..t_x;
+    equal to torch.nn.functional.ctc_loss on log_softmax(pad(logp)), reduction "none" (tests/test_objective.py)."""
     _lib.require_gpu()
     lp = _chk(logp, "logp")
     if lp.dim() != 3:
@@ -43,12 +47,19 @@ def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_g
     tx = _lengths(t_x, "t_x", B, dev)
     ty = _lengths(t_y, "t_y", B, dev)
     lib = _lib.load()
-    nws = lib.aligner_forward_sum_workspace_bytes(B, Tx, Ty)
+    ctc = blank_logprob is not None
+    nws = (lib.aligner_forward_sum_ctc_workspace_bytes if ctc else lib.aligner_forward_sum_workspace_bytes)(B, Tx, Ty)
     if nws == 0 and B > 0:
-        raise ValueError(f"unsupported shape B={B} T_text={Tx} T_mel={Ty} (T_text <= 1024)")
+        raise ValueError(f"unsupported shape B={B} T_text={Tx} T_mel={Ty} (T_text <= {1023 if ctc else 1024})")
     ws = _fs_workspace(dev, nws)
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     grad = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_grad else None
+    if ctc:
+        with torch.cuda.device(dev):
+            _lib.check(lib.aligner_forward_sum_ctc_f32(lp.data_ptr(), tx.data_ptr(), ty.data_ptr(), float(blank_logprob),
+                                                       loss.data_ptr(), None if grad is None else grad.data_ptr(),
+                                                       ws.data_ptr(), ws.numel(), B, Tx, Ty, _stream(dev)))
+        return loss, grad
     with torch.cuda.device(dev):
         _lib.check(lib.aligner_forward_sum_f32(lp.data_ptr(), tx.data_ptr(), ty.data_ptr(), loss.data_ptr(),
                                                None if grad is None else grad.data_ptr(), ws.data_ptr(), ws.numel(),

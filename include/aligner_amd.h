@@ -317,6 +317,21 @@ int aligner_forward_sum_f32(const float *logp_dev, const int32_t *t_xs_dev, cons
                             void *workspace_dev, size_t workspace_bytes,
                             int B, int Tx, int Ty, void *stream);
 
+/*
+ * The CTC form of the same objective -- the published one (OTA's forward-sum loss, README.md:21-25,50): a blank column
+ * of log-prob `blank_logprob` (-1 in the paper's code) is put before the text rows, every frame is renormalised over
+ * blank + the utterance's t_x text rows (log_softmax), and loss[b] = CTC loss of the token sequence 1..t_x over the
+ * t_y frames = torch.nn.functional.ctc_loss(log_softmax(pad(scores)), targets = 1..t_x, reduction = "none") -- which
+ * is what tests/test_objective.py checks it against, in float64.  grad_out_dev (optional) = d loss / d scores
+ * = softmax over blank + text of the frame - posterior occupancy of the token, 0 outside [0,t_x) x [0,t_y).
+ * scores_dev [B,Tx,Ty] fp32 (Tx <= 1023); loss +inf where t_x < 1 or t_x > t_y (no labelling exists; gradient 0).
+ */
+size_t aligner_forward_sum_ctc_workspace_bytes(int B, int Tx, int Ty);
+int aligner_forward_sum_ctc_f32(const float *scores_dev, const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                                float blank_logprob, float *loss_out_dev, float *grad_out_dev,
+                                void *workspace_dev, size_t workspace_bytes,
+                                int B, int Tx, int Ty, void *stream);
+
 /* prior[b,x,y] = BetaBinomial(n = t_x, a = scaling*(y+1), b = scaling*(t_y-y)).pmf(x) for x < t_x,
  * y < t_y, 0 elsewhere; [B,Tx,Ty] fp32, the `prior_dev` operand of aligner_softattn_f32. */
 int aligner_beta_binomial_prior_f32(const int32_t *t_xs_dev, const int32_t *t_ys_dev, float *prior_out_dev,

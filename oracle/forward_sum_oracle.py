@@ -85,3 +85,33 @@ def regulate(h: np.ndarray, durations: np.ndarray, Ty: int) -> np.ndarray:
         idx = np.repeat(np.arange(Tx), durations[b])[:Ty]
         out[b, :, :len(idx)] = h[b][:, idx]
     return out
+
+
+def ctc_forward_sum(scores: np.ndarray, tx, ty, blank_logprob: float = -1.0):
+    """The CTC form of the objective -- the published one -- through torch.nn.functional.ctc_loss in float64 on
+    the CPU: an EXTERNAL pin (torch's implementation, not this build's maths).  Exactly the OTA paper's public loss:
+    a blank column at `blank_logprob` before the text rows, log_softmax over blank + the utterance's text rows per
+    frame, CTC loss of the token sequence 1..t_x, reduction "none".  Returns (loss[B], d loss / d scores [B,Tx,Ty]);
+    utterances without a labelling (t_x < 1 or t_x > t_y) get loss inf and gradient 0."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.tensor(np.asarray(scores), dtype=torch.float64, requires_grad=True)
+    B = x.shape[0]
+    losses, tot = [], 0.0
+    for b in range(B):
+        K, T = int(tx[b]), int(ty[b])
+        if not (1 <= K <= T):
+            losses.append(float("inf"))
+            continue
+        lp = torch.cat([torch.full((1, T), float(blank_logprob), dtype=torch.float64), x[b, :K, :T]], dim=0)   # [K+1, T]
+        lp = torch.log_softmax(lp, dim=0).t().unsqueeze(1)                                                   # [T, 1, K+1]
+        l = F.ctc_loss(lp, torch.arange(1, K + 1).unsqueeze(0), torch.tensor([T]), torch.tensor([K]), blank=0,
+                       reduction="none", zero_infinity=False)[0]
+        losses.append(float(l))
+        tot = tot + l
+    if isinstance(tot, torch.Tensor):
+        tot.backward()
+        grad = x.grad.numpy()
+    else:
+        grad = np.zeros(x.shape, np.float64)
+    return np.asarray(losses, np.float64), grad

@@ -90,6 +90,28 @@ def test_regulate_oracle():
     assert np.array_equal(out[1, 2], [20, 21, 22, 23, 0, 0, 0])
 
 
+def test_ctc_oracle_is_torch_ctc_loss_and_reduces_to_known_cases():
+    """The CTC-form oracle is torch.nn.functional.ctc_loss (float64, CPU).  Sanity of the wiring: one token over T
+    frames with a blank so unlikely that it never fires is the plain sum of the frame log-probs, and brute force over
+    all labellings of a tiny case."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((1, 1, 5))
+    loss, grad = FS.ctc_forward_sum(x, [1], [5], blank_logprob=-200.0)
+    assert abs(loss[0]) < 1e-9 and np.abs(grad).max() < 1e-9               # softmax over {blank, token} is ~(0, 1)
+    # brute force: K = 2 tokens, T = 4 frames, alphabet {blank, 1, 2}: sum over frame labellings that collapse to (1, 2)
+    K, T, blank = 2, 4, -0.7
+    x = rng.standard_normal((1, K, T))
+    lp = np.concatenate([np.full((1, T), blank), x[0]], 0)
+    lp = lp - np.log(np.exp(lp).sum(0, keepdims=True))
+    tot = 0.0
+    for lab in itertools.product(range(K + 1), repeat=T):
+        col = [c for i, c in enumerate(lab) if c != 0 and (i == 0 or lab[i - 1] != c)]
+        if col == [1, 2]:
+            tot += np.exp(sum(lp[c, t] for t, c in enumerate(lab)))
+    loss, _ = FS.ctc_forward_sum(x, [K], [T], blank_logprob=blank)
+    assert abs(loss[0] + np.log(tot)) < 1e-10
+
+
 # --------------------------------------------------------------------------- HIP path (GPU)
 gpu = pytest.mark.gpu
 
@@ -205,3 +227,64 @@ def test_regulate_matches_oracle_and_the_path(dev):
     al = aligner_amd.align(lp, tx, ty, want_tok=True)
     _, tok2 = aligner_amd.regulate(torch.zeros((2, 1, 60), device=dev), al.durations, 400)
     assert torch.equal(tok2, al.tok)
+
+
+@gpu
+@pytest.mark.parametrize("B,Tx,Ty,ragged", [(3, 7, 19, True), (2, 1, 9, False), (4, 64, 200, True), (2, 200, 1000, False),
+                                             (2, 255, 600, True), (2, 256, 500, True), (1, 400, 900, True), (2, 33, 33, False),
+                                             (1, 600, 700, True)])
+@pytest.mark.parametrize("blank", [-1.0, -6.0])
+def test_forward_sum_ctc_form_matches_torch_ctc_loss(dev, B, Tx, Ty, ragged, blank):
+    """The published (CTC / blank) form of the forward-sum loss against torch.nn.functional.ctc_loss in float64 on the
+    CPU -- an external implementation -- loss and gradient, through the C ABI, with the tolerances of the plain form."""
+    import aligner_amd
+    rng = np.random.default_rng(B * 777 + Tx)
+    x = _rand_logp(rng, B, Tx, Ty)                                    # log-softmax'd attention, as the OTA model feeds it
+    if ragged:
+        ty = rng.integers(max(Tx // 2, 2), Ty + 1, size=B)
+        tx = np.minimum(rng.integers(1, Tx + 1, size=B), ty)
+        tx[0], ty[0] = Tx, Ty
+    else:
+        tx, ty = np.full(B, Tx), np.full(B, Ty)
+    want_loss, want_grad = FS.ctc_forward_sum(x, tx, ty, blank)
+    loss, grad = aligner_amd.forward_sum(torch.from_numpy(x).to(dev), torch.from_numpy(tx), torch.from_numpy(ty),
+                                         blank_logprob=blank)
+    torch.cuda.synchronize()
+    loss, grad = loss.cpu().numpy().astype(np.float64), grad.cpu().numpy().astype(np.float64)
+    # loss = -(log Z of the raw scores - sum of the frames' normalisers): two sums of ~T_mel fp32 log2 / exp2 results of
+    # magnitude ~|loss| each, so the absolute error scales with |loss|: 5e-4 + 1e-6 * |loss| (measured 1.1e-3 at 1 847)
+    assert (np.abs(loss - want_loss) <= 5e-4 + 1e-6 * np.abs(want_loss)).all()
+    # gradient = softmax - occupancy: the fp32 log-domain recursion carries a RELATIVE error in the occupancy (a number
+    # up to 1) that grows with the depth of the lattice -- two states per token, three-way sums: measured (tools/ctc_err.py)
+    # 7e-4 at [200,1000], 1.5e-3 at [255,600], 2.9e-3 at [400,900], 4.3e-3 at [600,700] -- so the difference is held to
+    # 5e-3 * occupancy + 2e-5 (the occupancy from the oracle)
+    x64 = x.astype(np.float64)
+    for b in range(B):
+        K, T = int(tx[b]), int(ty[b])
+        z = np.concatenate([np.full((1, T), blank), x64[b, :K, :T]], 0)
+        p = np.exp(z - np.log(np.exp(z).sum(0, keepdims=True)))[1:]
+        occ = p - want_grad[b, :K, :T]
+        assert occ.min() > -1e-9
+        assert (np.abs(grad[b, :K, :T] - want_grad[b, :K, :T]) <= 5e-3 * occ + 2e-5).all(), b
+    for b in range(B):
+        assert not grad[b, tx[b]:].any() and not grad[b, :, ty[b]:].any()
+        # per frame: softmax mass of the text rows minus the tokens' occupancy = occupancy(blank) - softmax(blank)
+        assert np.all(np.abs(grad[b, :tx[b], :ty[b]].sum(axis=0)) < 1.0 + 1e-3)
+
+
+@gpu
+def test_forward_sum_ctc_form_degenerate_and_loss_only(dev):
+    import aligner_amd
+    rng = np.random.default_rng(6)
+    x = _rand_logp(rng, 3, 10, 12)
+    tx, ty = np.array([10, 9, 0]), np.array([12, 8, 5])          # ok, fewer frames than tokens, no tokens
+    loss, grad = aligner_amd.forward_sum(torch.from_numpy(x).to(dev), torch.from_numpy(tx), torch.from_numpy(ty),
+                                         blank_logprob=-1.0)
+    loss2, none = aligner_amd.forward_sum(torch.from_numpy(x).to(dev), torch.from_numpy(tx), torch.from_numpy(ty),
+                                          want_grad=False, blank_logprob=-1.0)
+    torch.cuda.synchronize()
+    want, wgrad = FS.ctc_forward_sum(x, tx, ty, -1.0)
+    assert none is None and torch.equal(loss, loss2)
+    assert abs(float(loss[0]) - want[0]) < 1e-4 and torch.isinf(loss[1]) and torch.isinf(loss[2])
+    assert not grad[1].any() and not grad[2].any()
+    assert np.abs(grad[0].cpu().numpy() - wgrad[0]).max() < 1e-4
