@@ -539,7 +539,13 @@ __device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, con
 template <int VT, bool WANT_LA, int H, bool STAMPS>
 __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, T = blockDim.x;
+    // a launch that splits utterances (S > 1) carries one more wave: the HELPER takes the halo off the others' critical
+    // path -- it fetches the previous segment's row, waits for it if it must, and puts it into LDS (550-850 of a row's
+    // 3 300 cycles when wave 0 did it beside its own positions)
+    const int tid = threadIdx.x;
+    const bool has_helper = p.S > 1;
+    const int T = (int)blockDim.x - (has_helper ? 64 : 0);
+    const bool helper = tid >= T;
     const bool stamping = STAMPS && p.stamps != nullptr && tid == 0;      // (a build of its own: the stamps cost registers)
     unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_entry = 0, st_rt = 0, st_polls = 0, st_slow = 0;
     if (stamping) { st_entry = __builtin_amdgcn_s_memtime(); st_rt = __builtin_amdgcn_s_memrealtime(); }
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     mb_lds_barrier();                              // (the report slots are updated with atomics by every wave)
     const int pi = tid / H, sub = tid - pi * H;    // H consecutive lanes per position
     const int j1 = a + pi;
-    const bool mine = j1 < bnd;
+    const bool mine = !helper && j1 < bnd;
     const bool lead = mine && sub == 0;            // the lane of a position that writes its results
     float la = (j1 == 0) ? 0.f : MB_NEG, de = la;  // P(b_-1 = 0) = 1
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;
     unsigned *ring_out = p.ring + ((size_t)b * (p.S - 1) + (has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
     const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
-    const bool polls = sg > 0 && tid < D;
+    const int hl = tid - T;                        // helper: its lane
     const bool publishes = has_next && lead && j1 >= bnd - D;
     // this lane's part of a window: entries [w0, w1) of its D
     const int w0 = (sub * D) / H, w1 = ((sub + 1) * D) / H;
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     }
     auto dead_rows = [&](int from, int to) {      // rows without a reachable position: "log 0" everywhere
         for (int i = from; i < to; ++i) {
-            if (has_next)
+            if (has_next && !helper)
                 for (int h = tid; h < D; h += T) {
                     unsigned *r = ring_out + (size_t)i * 3 * D + h;
                     mb_ring_store(r, __builtin_bit_cast(unsigned, (float)MB_DEADM));
@@ -621,64 +627,135 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         return;
     }
     dead_rows(0, i0);
+    bool gave_up = false;
+    int R = 0;                                     // the row's reference for the fast sum (uniform: every wave tracks it)
+    int slot = 0;                                  // row index mod 3 (the waves' reports)
 
-    // operands of a row, all lanes, clamped addresses
+    if (helper) {
+        // ------------------------------ the helper wave: the halo of rows i0..i1 ------------------------------
+        if (sg > 0) {
+            if (p.start_lag > 0) {
+                // Let the segment before get `start_lag` rows ahead first.  A row's halo is fetched a row early; that
+                // only finds it if the producer is more than a row + the visibility latency ahead -- two segments in
+                // step pay a round trip to memory per row (measured: 1 200-3 000 cycles of every row).
+                int ig = i0 + p.start_lag;
+                ig = ig > I - 1 ? I - 1 : ig;
+                const unsigned *r = ring_in + (size_t)ig * 3 * D + (hl < D ? hl : 0) + 2 * D;    // the row's last word
+                int spins = 0;
+                while (mb_ring_load(r) == MB_FILL && !gave_up) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > p.spin_limit) gave_up = true;
+                }
+            }
+            const bool fetches = hl < D;
+            unsigned h0_nx, h1_nx, h2_nx;
+            auto issue_halo = [&](int i) {
+                const unsigned *r = fetches ? ring_in + (size_t)i * 3 * D + hl : trash;
+                const int st = fetches ? D : 0;
+                h0_nx = mb_ring_load(r);
+                h1_nx = mb_ring_load(r + st);
+                h2_nx = mb_ring_load(r + 2 * st);
+            };
+            issue_halo(i0);
+#pragma unroll 1
+            for (int i = i0; i <= i1; ++i) {
+                const unsigned h_c0 = h0_nx, h_c1 = h1_nx, h_c2 = h2_nx;
+                issue_halo(i + 1 < I ? i + 1 : I - 1);
+                const int bo = (i & 1) * W;
+                // this lane's own entry comes from the words fetched a row ago: its test must not share a join with a
+                // path that loads (hipcc would then wait vmcnt(0) here -- for the loads issued a moment ago)
+                int Mstat = MB_DEADM;
+                bool fits = true;
+                auto halo_entry = [&](int h, unsigned x0, unsigned x1, unsigned x2) {
+                    if (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) {          // not published yet: poll
+                        const unsigned *r = ring_in + (size_t)i * 3 * D + h;
+                        int spins = 0;
+                        do {
+                            __builtin_amdgcn_s_sleep(2);
+                            x0 = mb_ring_load(r);
+                            x1 = mb_ring_load(r + D);
+                            x2 = mb_ring_load(r + 2 * D);
+                            if (++spins > p.spin_limit) gave_up = true;
+                        } while ((x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) && !gave_up);
+                    }
+                    const bool bad = (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL);
+                    const int M = bad ? MB_DEADM : (int)__builtin_bit_cast(float, x0);
+                    const float sv = bad ? 0.f : __builtin_bit_cast(float, x1);
+                    sM[bo + h] = M;
+                    sS[bo + h] = sv;
+                    sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, x2);
+                    sT[bo + h] = __builtin_ldexpf(sv, M - R);
+                    if (M != MB_DEADM) {
+                        Mstat = Mstat > M ? Mstat : M;
+                        fits = fits && M >= R - 100 && M <= R + 100;
+                    }
+                };
+                if (fetches) halo_entry(hl, h_c0, h_c1, h_c2);
+                if (D > 64) {
+#pragma unroll 1
+                    for (int h = hl + 64; h < D; h += 64) halo_entry(h, MB_FILL, MB_FILL, MB_FILL);
+                }
+                {   // the wave's report: ONE LDS atomic each (a same-address atomic per lane serialises in the LDS pipe
+                    // and the barrier's lgkmcnt(0) waits for all of them: measured 1.03 -> 1.31 ms)
+                    const int wm = mb_wave_max_i32(Mstat);
+                    const bool wfit = __builtin_amdgcn_ballot_w64(!fits) == 0;
+                    if (hl == 0) {
+                        atomicMax(&sStat[2 * slot], wm);
+                        if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
+                    }
+                }
+                mb_lds_barrier();
+                const int Rn = sStat[2 * slot];
+                R = (Rn != MB_DEADM) ? Rn : R;
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        } else {
+#pragma unroll 1
+            for (int i = i0; i <= i1; ++i) mb_lds_barrier();                        // (segment 0 has no halo)
+        }
+        if (gave_up) {
+            atomicOr(p.status, ALIGNER_ST_INTERNAL);
+            p.failw[b] = 1;
+        }
+        return;
+    }
+
+    // ------------------------------ the compute waves ------------------------------
+    // operands of a row, all lanes, clamped addresses; pointers advance by a row
     const int je = (j1 < 1 ? 1 : (j1 > J ? J : j1)) - 1;               // frame of this lane's boundary position
     const int kl = j1 > J - 1 ? J - 1 : j1;                            // the step out of J does not exist (phase 1)
-    unsigned e_nx, h0_nx, h1_nx, h2_nx;
+    unsigned e_nx;
     float L_nx;
     auto issue = [&](int i) {
         const size_t ro = ubase + (size_t)i * p.Ty;
         e_nx = mb_load_raw<VT>(p.e, ro + je);
         L_nx = p.Lw[ro + kl];
-        const unsigned *r = polls ? ring_in + (size_t)i * 3 * D + tid : trash;
-        const int st = polls ? D : 0;
-        h0_nx = mb_ring_load(r);
-        h1_nx = mb_ring_load(r + st);
-        h2_nx = mb_ring_load(r + 2 * st);
     };
-    bool gave_up = false;
-    if (sg > 0 && p.start_lag > 0) {
-        // Let the segment before get `start_lag` rows ahead first.  A row's halo is fetched a row early (issue());
-        // that only finds it if the producer is more than a row + the visibility latency ahead -- two segments in
-        // step pay a round trip to memory per row (measured: 1 200-3 000 cycles of every row).
-        int ig = i0 + p.start_lag;
-        ig = ig > I - 1 ? I - 1 : ig;
-        const unsigned *r = ring_in + (size_t)ig * 3 * D + (tid < D ? tid : 0) + 2 * D;    // the row's last word
-        int spins = 0;
-        while (mb_ring_load(r) == MB_FILL && !gave_up) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > p.spin_limit) gave_up = true;
-        }
-    }
+    // without a helper wave (an unsplit launch) nobody else fetches a halo -- and there is none: S == 1
     issue(i0);
     // The loop is entered in the state every later row finds: the row's operand loads followed by four stores
     // (three ring words, one duration).  hipcc sizes a counted wait for the FEWEST operations that can follow on any
-    // path into it: without these four the halo's wait inside the loop came out as vmcnt(8) instead of vmcnt(12) and
-    // also waited for the previous row's stores to be acknowledged -- 1 200 cycles of every row.
+    // path into it: without these the waits inside the loop also waited for the previous row's stores to be
+    // acknowledged -- 1 200 cycles of every row.
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
     if (WANT_LA) mb_ring_store(trash, 0u);
-    int R = 0;                                     // the row's reference for the fast sum
-    int slot = 0;                                  // row index mod 3 (the waves' reports)
     unsigned long long st_loop = 0;
     if (stamping) { st_loop = st_t = __builtin_amdgcn_s_memtime(); }
 #pragma unroll 1
     for (int i = i0; i <= i1; ++i) {
         int lo, hi;
         mb_bounds(I, J, D, i, lo, hi);
-        const unsigned e_c = e_nx, h_c0 = h0_nx, h_c1 = h1_nx, h_c2 = h2_nx;
+        const unsigned e_c = e_nx;
         const float L_c = L_nx;
         issue(i + 1 < I ? i + 1 : I - 1);
         const size_t ro = ubase + (size_t)i * p.Ty;
         const int bo = (i & 1) * W;
-        if (stamping) { asm volatile("" :: "v"(e_c), "v"(L_c), "v"(h_c0)); }
+        if (stamping) { asm volatile("" :: "v"(e_c), "v"(L_c)); }
         MB_STAMP(0)
         // ---- phase 1: u = la_{i-1}(k) - L_i(k), v = delta_{i-1}(k) - L_i(k) ----
-        int Mstat = MB_DEADM;                      // largest live M this lane has seen in the row
-        bool fits = true;
         {
             const float L = (j1 < J) ? L_c : MB_NEG;
             const bool live = L > MB_DEADF;
@@ -694,9 +771,14 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 sS[x] = s;
                 sV[x] = v;
                 sT[x] = __builtin_ldexpf(s, M - R);
-                if (M != MB_DEADM) {
-                    Mstat = M;
-                    fits = M >= R - 100 && M <= R + 100;
+            }
+            {   // the wave's report about the row: largest live M, "an entry does not fit" -- one LDS atomic each
+                const bool livem = lead && M != MB_DEADM;
+                const int wm = mb_wave_max_i32(livem ? M : MB_DEADM);
+                const bool wfit = __builtin_amdgcn_ballot_w64(livem && !(M >= R - 100 && M <= R + 100)) == 0;
+                if ((tid & 63) == 0) {
+                    atomicMax(&sStat[2 * slot], wm);
+                    if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
                 }
             }
             unsigned *r = publishes ? ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
@@ -706,49 +788,6 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
             mb_ring_store(r + 2 * st, __builtin_bit_cast(unsigned, v));
         }
         MB_STAMP(1)
-        if (sg > 0) {
-            // this lane's own halo entry comes from the words fetched a row ago: its test must not share a join with a
-            // path that loads (hipcc would then wait vmcnt(0) here -- for the operand loads issued a moment ago)
-            auto halo_entry = [&](int h, unsigned x0, unsigned x1, unsigned x2) {
-                if (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) {          // not published yet: poll
-                    const unsigned *r = ring_in + (size_t)i * 3 * D + h;
-                    int spins = 0;
-                    do {
-                        __builtin_amdgcn_s_sleep(2);
-                        x0 = mb_ring_load(r);
-                        x1 = mb_ring_load(r + D);
-                        x2 = mb_ring_load(r + 2 * D);
-                        if (++spins > p.spin_limit) gave_up = true;
-                    } while ((x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL) && !gave_up);
-                    if (stamping) st_polls += (unsigned long long)spins;
-                }
-                const bool bad = (x0 == MB_FILL || x1 == MB_FILL || x2 == MB_FILL);
-                const int M = bad ? MB_DEADM : (int)__builtin_bit_cast(float, x0);
-                const float sv = bad ? 0.f : __builtin_bit_cast(float, x1);
-                sM[bo + h] = M;
-                sS[bo + h] = sv;
-                sV[bo + h] = bad ? MB_NEG : __builtin_bit_cast(float, x2);
-                sT[bo + h] = __builtin_ldexpf(sv, M - R);
-                if (M != MB_DEADM) {
-                    Mstat = Mstat > M ? Mstat : M;
-                    fits = fits && M >= R - 100 && M <= R + 100;
-                }
-            };
-            if (tid < D) halo_entry(tid, h_c0, h_c1, h_c2);
-            if (D > T) {
-#pragma unroll 1
-                for (int h = tid + T; h < D; h += T) halo_entry(h, MB_FILL, MB_FILL, MB_FILL);
-            }
-        }
-        MB_STAMP(6)
-        {   // what this wave reports about the row: one LDS atomic each into the row's slot (three slots in rotation)
-            const int wm = mb_wave_max_i32(Mstat);
-            const bool wfit = __builtin_amdgcn_ballot_w64(!fits) == 0;
-            if ((tid & 63) == 0) {
-                atomicMax(&sStat[2 * slot], wm);
-                if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
-            }
-        }
         MB_STAMP(2)
         mb_lds_barrier();
         MB_STAMP(3)
@@ -759,8 +798,6 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 const int nslot = slot == 0 ? 2 : slot - 1;         // (i + 2) % 3 when slot = i % 3
                 if (tid == 0) { sStat[2 * nslot] = MB_DEADM; sStat[2 * nslot + 1] = 0; }
             }
-            if (stamping) { asm volatile("" :: "s"(Rn), "s"(slow)); }
-            MB_STAMP(7)
             const float ev = mb_value<VT>(e_c) * MB_LOG2E;
             const bool feasible = mine && j1 >= lo && j1 <= hi;
             const int x = bo + (mine ? pi : 0) + w0;           // first entry of this lane's part
@@ -787,8 +824,6 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 }
                 if (acc > 0.f) lsum = (float)Mw + __builtin_amdgcn_logf(acc);
             }
-            if (stamping) { asm volatile("" :: "v"(lsum), "v"(best), "v"(qb)); }
-            MB_STAMP(8)
             qb += w0;
 #pragma unroll
             for (int m = 1; m < H; m <<= 1) {                  // the largest v; among equals the largest index
@@ -822,11 +857,6 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         MB_STAMP(5)
         slot = slot == 2 ? 0 : slot + 1;
     }
-    if (STAMPS && p.stamps != nullptr && (tid & 63) == 0 && (tid >> 6) < 6) {      // where each wave ran: HW_ID (+ XCC_ID)
-        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
-        p.stamps[(size_t)blockIdx.x * 24 + 18 + (tid >> 6)] = ((unsigned long long)xcc << 32) | hw;
-    }
     if (stamping) {
         unsigned long long *o = p.stamps + (size_t)blockIdx.x * 24;
         o[0] = st_entry; o[1] = st_loop; o[2] = __builtin_amdgcn_s_memtime();
@@ -859,10 +889,6 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         if (WANT_LA && lead && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
         dead_rows(i1 + 2, I);
         if (lead && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
-    }
-    if (gave_up) {
-        atomicOr(p.status, ALIGNER_ST_INTERNAL);
-        p.failw[b] = 1;
     }
 }
 
@@ -1034,6 +1060,11 @@ static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool
     if (g_opt_mobo_lanes == 1 || g_opt_mobo_lanes == 2 || g_opt_mobo_lanes == 4)       // development: force it
         if ((long long)nmax * g_opt_mobo_lanes <= 1024) pl.H = g_opt_mobo_lanes;
     pl.T = nmax <= 1024 ? (nmax * pl.H + 63) / 64 * 64 : 1024;
+    if (nmax <= 1024 && S > 1) {                   // the split form's helper wave (the halo): one more wave, at most 16 in all
+        if (pl.T + 64 > 1024) { pl.H = 1; pl.T = (nmax + 63) / 64 * 64; }
+        if (pl.T + 64 <= 1024) pl.T += 64;
+        else pl.NP = 2;                            // (1 024 positions in a split launch: the several-positions form)
+    }
     pl.lds = lds;
     int RB = 32;                                   // rows per backtrack batch: a power of two with RB^2 * D <= 32768
     while (RB > 1 && (long long)RB * RB * D > 32768) RB >>= 1;
