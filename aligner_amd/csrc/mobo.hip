@@ -158,15 +158,40 @@ __device__ __forceinline__ void mb_bounds(int I, int J, int D, int i, int &lo, i
 // row's loads and of this row's result stores on every row.
 __device__ __forceinline__ void mb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- cross-lane helpers of the split form -------------------------------------------------------------------
+__device__ __forceinline__ int mb_quad_xor_i(int v, int m) {       // the value of lane (lane ^ m), m = 1 or 2
+    return m == 1 ? __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float mb_quad_xor_f(float v, int m) {
+    return __builtin_bit_cast(float, mb_quad_xor_i(__builtin_bit_cast(int, v), m));
+}
+__device__ __forceinline__ int mb_wave_max_i32(int v) {            // maximum over the wave's 64 lanes (uniform result)
+#define MB_DPP_MAX(ctrl_, rows_)                                                          \
+    {                                                                                     \
+        const int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl_, rows_, 0xF, false);       \
+        v = v > o_ ? v : o_;                                                              \
+    }
+    MB_DPP_MAX(0x111, 0xF)      // row_shr:1
+    MB_DPP_MAX(0x112, 0xF)      // row_shr:2
+    MB_DPP_MAX(0x114, 0xF)      // row_shr:4
+    MB_DPP_MAX(0x118, 0xF)      // row_shr:8   -> lane 15 of every row holds its row's maximum
+    MB_DPP_MAX(0x142, 0xA)      // row_bcast:15 into rows 1 and 3
+    MB_DPP_MAX(0x143, 0xC)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+#undef MB_DPP_MAX
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 1. L_i(k) for every (utterance, token, position); also refills the ring and clears the give-up words.
 //    grid (ceil(Ty/256), Tx, B) x 256 threads, one position k per thread, window (k, k+D] read from LDS.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int MB_NCH = 1024;                      // positions per workgroup of the normaliser kernel (4 per thread)
+
 template <int VT>
 __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned long long ring_words) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, i = blockIdx.y, k0 = blockIdx.x * 256;
+    const int b = blockIdx.z, i = blockIdx.y, k0 = blockIdx.x * MB_NCH;
     {   // housekeeping spread over the whole grid
         const unsigned long long nthr = (unsigned long long)gridDim.x * gridDim.y * gridDim.z * 256ull;
         const unsigned long long gid = (((unsigned long long)b * gridDim.y + i) * gridDim.x + blockIdx.x) * 256ull + tid;
@@ -178,10 +203,10 @@ __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned l
     I = I > p.Tx ? p.Tx : I;
     J = J > p.Ty ? p.Ty : J;
     const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
-    const int k = k0 + tid;
     const size_t rowoff = ((size_t)b * p.Tx + i) * p.Ty;
     if (!ok || i >= I) {                              // nothing to search here: only the padding of log_alpha
-        if (p.log_alpha && k < p.Ty) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+        if (p.log_alpha)
+            for (int k = k0 + tid; k < k0 + MB_NCH && k < p.Ty; k += 256) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
         return;
     }
     int lo, hi;
@@ -193,17 +218,22 @@ __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned l
         const long long reach = (long long)i * D;
         if (khi > reach) khi = (int)reach;
     }
-    if (k0 > khi || k0 + 255 < klo) {                 // the whole block is outside the band
-        if (k < p.Ty) {
+    if (k0 > khi || k0 + MB_NCH - 1 < klo) {          // the whole block is outside the band
+        for (int k = k0 + tid; k < k0 + MB_NCH && k < p.Ty; k += 256) {
             p.Lw[rowoff + k] = MB_NEG;
             if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
         }
         return;
     }
+    const int NE = MB_NCH + D;                        // staged entries
     int *sM = reinterpret_cast<int *>(smem);
-    float *sS = reinterpret_cast<float *>(sM + 256 + D);
-    // entries x = 0 .. 255+D-1 stand for boundary positions m = k0+1+x, i.e. frames m-1
-    for (int x = tid; x < 256 + D; x += 256) {
+    float *sS = reinterpret_cast<float *>(sM + NE);
+    float *sT = sS + NE;
+    __shared__ int s_blockmax;
+    if (tid == 0) s_blockmax = MB_DEADM;
+    // entries x = 0 .. NE-1 stand for boundary positions m = k0+1+x, i.e. frames m-1
+    int Mmax = MB_DEADM;
+    for (int x = tid; x < NE; x += 256) {
         const int m = k0 + 1 + x;
         float e2 = MB_NEG;
         if (m >= lo && m <= hi) e2 = mb_value<VT>(mb_load_raw<VT>(p.e, rowoff + (m - 1))) * MB_LOG2E;
@@ -212,18 +242,49 @@ __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned l
         mb_encode(e2, M, s);
         sM[x] = M;
         sS[x] = s;
+        Mmax = Mmax > M ? Mmax : M;
     }
     __syncthreads();
-    if (k >= p.Ty) return;
-    float L = MB_NEG;
-    if (k < J && k >= klo && k <= khi) {
-        int Mw, qb;
-        float acc, best;
-        mb_window<false>(sM + tid, sS + tid, nullptr, D, Mw, acc, best, qb);
-        if (acc > 0.f) L = (float)Mw + __builtin_amdgcn_logf(acc);
+    {   // the block's largest M (one LDS atomic per wave)
+        const int wm = mb_wave_max_i32(Mmax);
+        if ((tid & 63) == 0) atomicMax(&s_blockmax, wm);
     }
-    p.Lw[rowoff + k] = L;
-    if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+    __syncthreads();
+    // FAST sums: every term as a plain float against the block's largest M -- exact while every live entry is within
+    // 100 of it (the energies of a thousand neighbouring frames of one token: always, on real log-likelihoods); a
+    // block with an entry further down takes the exact (M, s) sums
+    const int Rb = s_blockmax;
+    bool fits = true;
+    for (int x = tid; x < NE; x += 256) {
+        const int M = sM[x];
+        sT[x] = __builtin_ldexpf(sS[x], M - Rb);
+        if (M != MB_DEADM && M < Rb - 100) fits = false;
+    }
+    const int slow = __syncthreads_or(!fits);
+#pragma unroll 1
+    for (int q = 0; q < MB_NCH / 256; ++q) {
+        const int x0 = tid + 256 * q, k = k0 + x0;
+        if (k >= p.Ty) break;
+        float L = MB_NEG;
+        if (k < J && k >= klo && k <= khi) {
+            if (!slow) {
+                float acc = 0.f;
+                const float *t = sT + x0;
+                int c = 0;
+                for (; c + 8 <= D; c += 8)
+                    acc += ((t[c] + t[c + 1]) + (t[c + 2] + t[c + 3])) + ((t[c + 4] + t[c + 5]) + (t[c + 6] + t[c + 7]));
+                for (; c < D; ++c) acc += t[c];
+                if (acc > 0.f) L = (float)Rb + __builtin_amdgcn_logf(acc);
+            } else {
+                int Mw, qb;
+                float acc, best;
+                mb_window<false>(sM + x0, sS + x0, nullptr, D, Mw, acc, best, qb);
+                if (acc > 0.f) L = (float)Mw + __builtin_amdgcn_logf(acc);
+            }
+        }
+        p.Lw[rowoff + k] = L;
+        if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -453,32 +514,8 @@ __global__ __launch_bounds__(1024) void mobo_chain_kernel(MoboParams p) {
     }
 }
 
-// ---- cross-lane helpers of the split form -------------------------------------------------------------------
-__device__ __forceinline__ int mb_quad_xor_i(int v, int m) {       // the value of lane (lane ^ m), m = 1 or 2
-    return m == 1 ? __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
-}
-__device__ __forceinline__ float mb_quad_xor_f(float v, int m) {
-    return __builtin_bit_cast(float, mb_quad_xor_i(__builtin_bit_cast(int, v), m));
-}
-__device__ __forceinline__ int mb_wave_max_i32(int v) {            // maximum over the wave's 64 lanes (uniform result)
-#define MB_DPP_MAX(ctrl_, rows_)                                                          \
-    {                                                                                     \
-        const int o_ = __builtin_amdgcn_update_dpp(v, v, ctrl_, rows_, 0xF, false);       \
-        v = v > o_ ? v : o_;                                                              \
-    }
-    MB_DPP_MAX(0x111, 0xF)      // row_shr:1
-    MB_DPP_MAX(0x112, 0xF)      // row_shr:2
-    MB_DPP_MAX(0x114, 0xF)      // row_shr:4
-    MB_DPP_MAX(0x118, 0xF)      // row_shr:8   -> lane 15 of every row holds its row's maximum
-    MB_DPP_MAX(0x142, 0xA)      // row_bcast:15 into rows 1 and 3
-    MB_DPP_MAX(0x143, 0xC)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
-#undef MB_DPP_MAX
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
 // One part of a window for the FAST sum: plain fp32 terms t = 2^(u - R) against the row's common reference R (see
-// the kernel), and the same maximum search as mb_window.  (Groups of 16 with the position of the maximum found in
-// registers measured slower: 1 300 against 1 010 cycles per row.)
+// the kernel), and the same maximum search as mb_window (the position of a group's maximum is found in the registers).
 __device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, const float *__restrict__ sV, int cnt,
                                                float &acc, float &best, int &qbest) {
     acc = 0.f;
@@ -494,7 +531,6 @@ __device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, con
             qbest = c;
         }
     }
-    int cbest = -1;
     for (; c < cnt; c += 8) {
         float t[8], v[8];
 #pragma unroll
@@ -506,15 +542,13 @@ __device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, con
         float vm = v[0];
 #pragma unroll
         for (int u = 1; u < 8; ++u) vm = __builtin_fmaxf(vm, v[u]);
+        int qi = 0;                                     // the last entry of the group that equals its maximum
+#pragma unroll
+        for (int u = 1; u < 8; ++u) qi = (v[u] == vm) ? u : qi;
         if (vm >= best) {
             best = vm;
-            cbest = c;
+            qbest = c + qi;
         }
-    }
-    if (cbest >= 0) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (sV[cbest + u] == best) qbest = cbest + u;
     }
 }
 
@@ -772,10 +806,13 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 sV[x] = v;
                 sT[x] = __builtin_ldexpf(s, M - R);
             }
-            {   // the wave's report about the row: largest live M, "an entry does not fit" -- one LDS atomic each
+            {   // the wave's report about the row -- one LDS atomic each: "an entry does not fit", and a candidate for the
+                // next row's reference: the M of ANY live lane will do (while the row fits, every live M is within 100 of
+                // R and so of one another; a wave-wide maximum costs six DPP steps a row)
                 const bool livem = lead && M != MB_DEADM;
-                const int wm = mb_wave_max_i32(livem ? M : MB_DEADM);
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(livem);
                 const bool wfit = __builtin_amdgcn_ballot_w64(livem && !(M >= R - 100 && M <= R + 100)) == 0;
+                const int wm = lm ? __builtin_amdgcn_readlane(M, __builtin_ctzll(lm)) : MB_DEADM;
                 if ((tid & 63) == 0) {
                     atomicMax(&sStat[2 * slot], wm);
                     if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
@@ -1131,9 +1168,9 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
                  reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, pl.D, pl.S, pl.nmax, pl.bstride, g_opt_mobo_start_lag, g_debug_stamps,
                  g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
     {   // 1. normalisers (+ ring refill)
-        const size_t nlds = (size_t)(256 + pl.D) * 8;
+        const size_t nlds = (size_t)(MB_NCH + pl.D) * 12;
         if (nlds > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "max_duration %d needs %zu bytes of LDS", pl.D, nlds);
-        const dim3 grid((Ty + 255) / 256, Tx, B);
+        const dim3 grid((Ty + MB_NCH - 1) / MB_NCH, Tx, B);
         auto launch = [&](auto kern) -> int {
             ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), nlds));
             hipLaunchKernelGGL(kern, grid, dim3(256), nlds, s, p, (unsigned long long)pl.ring_words);

@@ -26,11 +26,11 @@ t0 = s[:nblk, 0].min()
 clk = (s[:nblk, 2] - s[:nblk, 0]) / np.maximum((s[:nblk, 12] - s[:nblk, 11]) / 100e6, 1e-9) / 1e9
 print("shader clock GHz (median)", round(float(np.median(clk)), 3))
 names = ["operands ready", "phase 1 + publish", "halo", "(to barrier)", "barrier", "phase 2", "stores"]
-print("seg  entry  loop_start   end   rows first |  per-row cycles: wait-operands  phase1  halo  barrier  phase2  stores")
+print("seg  entry  loop_start   end   rows first |  per-row cycles: operands  phase1+report  -  barrier(waits for the helper)  phase2  stores")
 for sg in list(range(0, S, max(1, S // 8))) + [S - 1]:
     r = s[sg]   # utterance 0
     rows = max(r[9], 1)
-    print(f"{sg:3d} {r[0]-t0:7.0f} {r[1]-t0:9.0f} {r[2]-t0:9.0f} {int(r[9]):5d} {int(r[10]):5d} | " + " ".join(f"{r[3+q]/rows:8.0f}" for q in range(6)) + f"   polls/row {r[13]/rows:.2f} exact-sum rows {int(r[14])} | halo-entry {r[15]/rows:.0f} (rest of halo = wave report) | stats-read {r[16]/rows:.0f} window {r[17]/rows:.0f} (rest of phase2 = combine)")
+    print(f"{sg:3d} {r[0]-t0:7.0f} {r[1]-t0:9.0f} {r[2]-t0:9.0f} {int(r[9]):5d} {int(r[10]):5d} | " + " ".join(f"{r[3+q]/rows:8.0f}" for q in range(6)) + f"   polls/row {r[13]/rows:.2f} exact-sum rows {int(r[14])}")
 print("kernel span (cycles, first entry to last end):", int(s[:nblk, 2].max() - t0), "=", round((s[:nblk, 2].max() - t0) / np.median(clk) / 1e3, 1), "us")
 
 hw = st.cpu().numpy()[:nblk, 18:24]
