@@ -600,6 +600,9 @@ def main():
                          "cost 8 %% of the step rate on one rank (the RCCL kernel takes CUs from the batches in flight), "
                          "every 96 steps 1.5 %%")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-kernels", action="store_true",
+                    help="skip the event timings of the kernels the default step does not use (profiling passes: keeps the "
+                         "per-kernel counters of the search kernel unmixed)")
     ap.add_argument("--no-repeats", dest="repeats", action="store_false",
                     help="skip the four extra timed regions (spread) and the one-batch-in-flight figure")
     ap.add_argument("--no-stream-path", action="store_true", help="ordinary stores for the dense path in every run")
@@ -785,9 +788,10 @@ def main():
         t_sim = event_time_us(step.softattn, it, dev)
         t_fwd = event_time_us(step.forward, it, dev)
         t_exp = event_time_us(step.expand, it, dev)
-        t_full = event_time_us(step.search_with_path, it, dev)
-        t_zero = event_time_us(step.zero_path, it, dev)
-        t_scat = event_time_us(step.scatter_path, it, dev)
+        side_on = not args.no_side_kernels
+        t_full = event_time_us(step.search_with_path, it, dev) if side_on else float("nan")
+        t_zero = event_time_us(step.zero_path, it, dev) if side_on else float("nan")
+        t_scat = event_time_us(step.scatter_path, it, dev) if side_on else float("nan")
         cells = B * TX * TY
         kernels = {
             "softattn_kernel": {"us": t_sim, "bytes": 4 * B * C_ATT * (TX + TY) + 4 * cells},
@@ -803,7 +807,7 @@ def main():
         # command (tools/pmc_traffic.py; gfx950 FETCH_SIZE correction applied) and committed under profiles/ --
         # not measured by this run, so the line names the file (and with it the build) the figure comes from
         traffic, traffic_src = None, None
-        for name in ("r02h_pmc_hbm_traffic.json", "r02f_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        for name in ("r03_pmc_hbm_traffic.json", "r02h_pmc_hbm_traffic.json", "r02f_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
@@ -824,7 +828,7 @@ def main():
                                         "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                                         "frac_of_8000": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
                                         "frac_of_6300_achievable": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / 6300.0, 3)}
-                                    for k, v in {**kernels, **side}.items()}}
+                                    for k, v in {**kernels, **(side if side_on else {})}.items()}}
         out = {
             "metric": "aligned utterances/sec + frames/sec, [B=64,T_text=200,T_mel=1000]",
             "value": round(ups, 1), "unit": "utterances/s", "frames_per_s": round(ups * TY, 1),
