@@ -107,7 +107,7 @@ def ctc_forward_sum(scores: np.ndarray, tx, ty, blank_logprob: float = -1.0):
         lp = torch.log_softmax(lp, dim=0).t().unsqueeze(1)                                                   # [T, 1, K+1]
         l = F.ctc_loss(lp, torch.arange(1, K + 1).unsqueeze(0), torch.tensor([T]), torch.tensor([K]), blank=0,
                        reduction="none", zero_infinity=False)[0]
-        losses.append(float(l))
+        losses.append(float(l.detach()))
         tot = tot + l
     if isinstance(tot, torch.Tensor):
         tot.backward()

@@ -181,23 +181,53 @@ def test_forward_sum_prior_regulator_writes_stay_inside_their_buffers(dev, B, Tx
     assert float((post - 1).abs().max()) < 2e-3
 
 
-@pytest.mark.parametrize("B,Tx,Ty,D", [(2, 5, 9, 3), (2, 40, 300, 16), (1, 100, 600, 7), (2, 64, 257, 32)])
-def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D):
+@pytest.mark.parametrize("B,Tx,Ty,D", [(2, 5, 9, 3), (2, 40, 300, 16), (1, 100, 600, 7), (2, 64, 257, 32), (3, 33, 700, 40),
+                                       (1, 6, 2600, 1300), (1, 120, 1000, 16)])
+@pytest.mark.parametrize("exact_ws", [False, True])
+def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, exact_ws):
+    """Normalisers, the segmented chain (ring, trash area, per-(token, position) durations), backtrack and gamma kernels:
+    ragged lengths, one and many segments per utterance, several positions per thread; with the workspace of the
+    window-independent bound and with exactly aligner_boundary_search_workspace_bytes_ex bytes."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(Tx + Ty + D)
     e = torch.randn(B, Tx, Ty, generator=g).to(dev)
-    t_x = torch.full((B,), Tx, dtype=torch.int32, device=dev)
-    t_y = torch.full((B,), Ty, dtype=torch.int32, device=dev)
-    wsb = lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty)
+    tx = [Tx] + [max(-(-Ty // (2 * D)), Tx - 3 * i) for i in range(1, B)]
+    ty = [min(Ty, Tx * D)] + [min(Ty - 7 * i, tx[i] * D) for i in range(1, B)]
+    t_x = torch.tensor(tx, dtype=torch.int32, device=dev)
+    t_y = torch.tensor(ty, dtype=torch.int32, device=dev)
+    wsb = lib.aligner_boundary_search_workspace_bytes_ex(B, Tx, Ty, D) if exact_ws else lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty)
+    assert 0 < wsb and lib.aligner_boundary_search_workspace_bytes_ex(B, Tx, Ty, D) <= lib.aligner_boundary_search_workspace_bytes(B, Tx, Ty)
     ws, bnd, dur, sc = Fenced(wsb, dev), Fenced(B * Tx * 4, dev), Fenced(B * Tx * 4, dev), Fenced(B * 4, dev)
     la, gm = Fenced(B * Tx * Ty * 4, dev), Fenced(B * Tx * Ty * 4, dev)
-    _lib.check(lib.aligner_boundary_search(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, bnd.ptr, dur.ptr, sc.ptr,
-                                           la.ptr, gm.ptr, ws.ptr, wsb, B, Tx, Ty, torch.cuda.current_stream().cuda_stream))
+    for _ in range(2):                                   # twice: the second call meets the first one's ring and counters
+        _lib.check(lib.aligner_boundary_search(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, bnd.ptr, dur.ptr,
+                                               sc.ptr, la.ptr, gm.ptr, ws.ptr, wsb, B, Tx, Ty,
+                                               torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     for name, f in (("workspace", ws), ("boundaries", bnd), ("durations", dur), ("score", sc), ("log_alpha", la), ("gamma", gm)):
         assert f.intact(), f"{name}: a kernel wrote outside its buffer"
     d = dur.view(torch.int32, (B, Tx))
-    assert bool((d >= 1).all()) and bool((d <= D).all()) and bool((d.sum(1) == Ty).all())
+    for b in range(B):
+        db = d[b, :tx[b]]
+        assert bool((db >= 1).all()) and bool((db <= D).all()) and int(db.sum()) == ty[b]
+    assert int(ws.view(torch.int32, (wsb // 4,))[0]) == 0          # status word
+
+
+@pytest.mark.parametrize("B,Tx,Ty", [(2, 9, 40), (2, 200, 1000), (2, 255, 400), (1, 300, 500), (1, 600, 900)])
+def test_forward_sum_ctc_form_writes_stay_inside_their_buffers(dev, B, Tx, Ty):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tx * 5 + Ty)
+    x = torch.log_softmax(torch.randn(B, Tx, Ty, generator=g), dim=1).to(dev)
+    t_x = torch.tensor([Tx] + [max(1, Tx - 5 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    t_y = torch.tensor([Ty] + [max(Tx, Ty - 11 * i) for i in range(1, B)], dtype=torch.int32, device=dev)
+    wsb = lib.aligner_forward_sum_ctc_workspace_bytes(B, Tx, Ty)
+    ws, loss, grad = Fenced(wsb, dev), Fenced(B * 4, dev), Fenced(B * Tx * Ty * 4, dev)
+    _lib.check(lib.aligner_forward_sum_ctc_f32(x.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), -1.0, loss.ptr, grad.ptr, ws.ptr, wsb,
+                                               B, Tx, Ty, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for name, f in (("workspace", ws), ("loss", loss), ("grad", grad)):
+        assert f.intact(), f"{name}: a CTC-form kernel wrote outside its buffer"
+    assert bool(torch.isfinite(loss.view(torch.float32, (B,))).all())
 
 
 @pytest.mark.parametrize("B,C,Tx,Ty", [(2, 80, 50, 130), (2, 80, 200, 1000), (1, 80, 252, 2048)])
