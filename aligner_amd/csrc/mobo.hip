@@ -996,7 +996,9 @@ __global__ __launch_bounds__(256) void mobo_backtrack_kernel(MoboParams p, int R
                 const int d = w16[(size_t)t * wp * 8 + (jj - (first & ~7))];
                 s_b[t] = jj;
                 s_d[t] = d;
-                if (d < 1 || d > D || d > jj) { s_bad = 1; jj = 0; break; }
+                // the very first look-up finding no duration: P(b_{I-1} = J) = 0 -- masked (-inf) energies leave no
+                // segmentation with positive probability.  Not an internal error: reported like an infeasible length
+                if (d < 1 || d > D || d > jj) { s_bad = (i == I - 1 && t == 0 && d == 0) ? 2 : 1; jj = 0; break; }
                 jj -= d;
             }
             s_j = jj;
@@ -1009,7 +1011,16 @@ __global__ __launch_bounds__(256) void mobo_backtrack_kernel(MoboParams p, int R
         }
         __syncthreads();
     }
-    if (tid == 0 && (s_bad || s_j != 0)) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+    if (s_bad) {                                   // no (or no consistent) sequence: all-zero outputs, as for an infeasible length
+        for (int i = tid; i < p.Tx; i += 256) {
+            bo[i] = 0;
+            if (du) du[i] = 0;
+        }
+        if (p.map_score && tid == 0) p.map_score[b] = -__builtin_huge_valf();
+        if (tid == 0) atomicOr(p.status, s_bad == 2 ? ALIGNER_ST_BAD_LENGTHS : ALIGNER_ST_INTERNAL);
+    } else if (tid == 0 && s_j != 0) {
+        atomicOr(p.status, ALIGNER_ST_INTERNAL);
+    }
 }
 
 // gamma[i,y] = P(b_{i-1} <= y) - P(b_i <= y) from the forward variables: one workgroup per (utterance, token),

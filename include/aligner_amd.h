@@ -357,8 +357,9 @@ int aligner_regulate_f32(const float *h_dev, const int32_t *durations_dev, float
  *   gamma_out_dev      optional [B,Tx,Ty] fp32 soft alignment P(b_{i-1} <= y < b_i); needs log_alpha_out_dev
  *   workspace_dev      aligner_boundary_search_workspace_bytes_ex(B,Tx,Ty,max_duration) bytes (the form without
  *                      max_duration is an upper bound for every window), first 256 zeroed once (status word as for
- *                      aligner_maxpath: ALIGNER_ST_BAD_LENGTHS for an utterance without any segmentation, i.e. not
- *                      t_x <= t_y <= t_x*max_duration; its outputs are 0 / -inf).  It holds the normalisers
+ *                      aligner_maxpath: ALIGNER_ST_BAD_LENGTHS for an utterance without any segmentation -- not
+ *                      t_x <= t_y <= t_x*max_duration, or masked (-inf) energies that leave no boundary sequence a
+ *                      positive probability; its outputs are 0 / -inf).  It holds the normalisers
  *                      [B,Tx,Ty] fp32, the per-(token, position) durations [B,Tx,Ty+1] u16 and the ring through
  *                      which the position segments of an utterance hand their last max_duration entries on.
  * Three launches: normalisers of every (utterance, token, position) on the whole chip; the token chain with an

@@ -198,3 +198,27 @@ def test_boundary_search_segment_that_never_delivers_fails_loudly(dev):
     again = aligner_amd.boundary_search(e, tx, ty, 32)          # and the next call is fine
     torch.cuda.synchronize()
     assert mobo.read_status(dev) == 0 and torch.equal(again.boundaries, good.boundaries)
+
+
+@gpu
+def test_boundary_search_masked_frames_without_any_segmentation(dev):
+    """Masked (-inf) energies can leave no boundary sequence a positive probability (here: every token's last admissible
+    frame is masked in a tight utterance).  That is an input without an answer, not an internal error: all-zero
+    boundaries / durations, map_score -inf, ALIGNER_ST_BAD_LENGTHS -- and the batch's other utterances are untouched.
+    (Found by tools/soak_mobo.py: the first build reported ALIGNER_ST_INTERNAL.)"""
+    import aligner_amd
+    from aligner_amd import mobo
+    rng = np.random.default_rng(31)
+    B, Tx, Ty, D = 3, 4, 8, 2
+    e = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    e[1, 3, 7] = -np.inf                                  # 4 tokens x 2 frames = 8: token 3 must end at frame 7
+    tx, ty = np.array([4, 4, 4], np.int32), np.array([8, 8, 7], np.int32)
+    assert not np.isfinite(M.boundary_search_fast(e[1].astype(np.float64), D)["map_score"])
+    r = aligner_amd.boundary_search(torch.from_numpy(e).to(dev), torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True)
+    torch.cuda.synchronize()
+    assert mobo.read_status(dev) == 1
+    assert not r.durations[1].any() and not r.boundaries[1].any() and torch.isneginf(r.map_score[1])
+    for b in (0, 2):
+        want = M.boundary_search_fast(e[b, :tx[b], :ty[b]].astype(np.float64), D)
+        assert np.array_equal(r.boundaries[b].cpu().numpy()[:tx[b]], want["boundaries"])
+        assert abs(float(r.map_score[b]) - want["map_score"]) < 1e-3
