@@ -57,10 +57,16 @@ def main():
         want = oracle(v, tx, ty, neg)
         vd = torch.from_numpy(v).to(dev)
         txd, tyd = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
-        for name, kw in (("auto", {}), ("generic", {"force_generic": True})):
-            if name == "generic" and it % 4:
+        pdt = [torch.int32, torch.float32, torch.uint8, torch.bfloat16, torch.int64][int(rng.integers(0, 5))]
+        # auto: the dense path inside the search launch (zero workgroups) where it applies; separate: the expand kernel;
+        # prezeroed: the caller's zeros + the search kernel's ones
+        for name, kw in (("auto", {}), ("generic", {"force_generic": True}), ("separate_expand", {"_test_flags": 4096}),
+                         ("prezeroed", {"out_path_is_zero": True})):
+            if name != "auto" and (it + len(name)) % 4:
                 continue
-            got = aligner_amd.align(vd, txd, tyd, path_dtype=torch.int32, max_neg_val=neg, **kw).path.cpu().numpy()
+            if name == "prezeroed":
+                kw = dict(kw, out_path=torch.zeros((B, Tx, Ty), dtype=pdt, device=dev))
+            got = aligner_amd.align(vd, txd, tyd, path_dtype=pdt, max_neg_val=neg, **kw).path.to(torch.int32).cpu().numpy()
             if not np.array_equal(got, want):
                 bad += 1
                 print(f"MISMATCH case {it} kernel {name}: B={B} Tx={Tx} Ty={Ty} kind={kind} neg={neg} tx={tx} ty={ty}", flush=True)
