@@ -214,7 +214,9 @@ void aligner_debug_set_stamps(void *stamps_dev);
  * ALIGNER_SOFTATTN_EXACT, read once at load): "fwdsum_one_wave" forces the one-sweeping-wave forward-sum
  * kernels, "softattn_exact" the exact-product similarity kernel; "mobo_drop_segment" (a segment index, -1 = off)
  * makes that position segment of every utterance withhold its rows from the next one, which then gives up after a
- * short wait: the test of the boundary search's defined failure.  ALIGNER_EINVAL for an unknown name. */
+ * short wait: the test of the boundary search's defined failure; "mobo_start_lag" (rows a position segment lets the
+ * one before it get ahead, default 1) and "mobo_lanes" (lanes per position of the split form: 1, 2, 4; 0 = the plan's
+ * choice) are the boundary search's measurement knobs (tools/mobo_time.py).  ALIGNER_EINVAL for an unknown name. */
 int aligner_debug_set_option(const char *name, int value);
 
 /*
