@@ -78,6 +78,8 @@ SIGNATURES = {
     "aligner_boundary_search_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_boundary_search_workspace_bytes_ex": (_sz, [_i, _i, _i, _i]),
     "aligner_boundary_search": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "aligner_boundary_search_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "aligner_boundary_search_backward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_regulate_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 

@@ -1066,6 +1066,8 @@ __global__ __launch_bounds__(256) void mobo_gamma_kernel(const float *__restrict
     }
 }
 
+#include "mobo_bwd.inc"
+
 // ---------------------------------------------------------------------------------------------------------
 // launch plan: D, segments per utterance, positions per segment, threads, workspace layout
 // ---------------------------------------------------------------------------------------------------------
@@ -1130,11 +1132,126 @@ static int mobo_plan(int B, int Tx, int Ty, int max_duration, MoboPlan &pl, bool
     return ALIGNER_OK;
 }
 
+// the gradient's launch plan: the search's segments, its own workspace
+struct MoboBwdPlan {
+    MoboPlan f;
+    int T;
+    bool multi;
+    size_t lds, ring_words;
+    size_t status_off, fail_off, trash_off, L_off, U_off, Q_off, G_off, Y_off, ring_off, total;
+};
+static int mobo_bwd_plan(int B, int Tx, int Ty, int max_duration, MoboBwdPlan &pl, bool quiet) {
+    const int rc = mobo_plan(B, Tx, Ty, max_duration, pl.f, quiet);
+    if (rc) return rc;
+    const MoboPlan &f = pl.f;
+    pl.multi = f.nmax > 1024;
+    pl.T = pl.multi ? 1024 : (f.nmax + 63) / 64 * 64;
+    pl.lds = (size_t)2 * 2 * 4 * ((size_t)f.nmax + f.D) + (pl.multi ? (size_t)4 * f.nmax : 0);      // <= the search's
+    pl.ring_words = (size_t)B * (f.S - 1) * Tx * 2 * f.D;
+    const size_t cells = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
+    pl.status_off = 0;
+    pl.fail_off = 256;
+    pl.trash_off = align_up(pl.fail_off + (size_t)B * sizeof(int), 256);
+    pl.L_off = align_up(pl.trash_off + ((size_t)B * f.S * 1024 + 64) * sizeof(unsigned), 256);
+    pl.U_off = pl.L_off + cells;
+    pl.Q_off = pl.U_off + cells;
+    pl.G_off = pl.Q_off + cells;
+    pl.Y_off = pl.G_off + cells;
+    pl.ring_off = pl.Y_off + cells;
+    pl.total = align_up(pl.ring_off + pl.ring_words * sizeof(unsigned), 256);
+    return ALIGNER_OK;
+}
+
 }  // namespace aligner
 
 using namespace aligner;
 
 extern "C" {
+
+size_t aligner_boundary_search_backward_workspace_bytes(int B, int Tx, int Ty, int max_duration) {
+    if (B < 0 || Tx < 1 || Ty < 1 || max_duration < 1) return 0;
+    MoboBwdPlan pl;
+    if (mobo_bwd_plan(B, Tx, Ty, max_duration, pl, true) != ALIGNER_OK) return 0;
+    return pl.total;
+}
+
+int aligner_boundary_search_backward(const void *energies, int energy_dtype, const int32_t *t_xs, const int32_t *t_ys,
+                                     int max_duration, const float *log_alpha, const float *grad_log_alpha,
+                                     const float *grad_gamma, float *grad_energies_out, void *workspace,
+                                     size_t workspace_bytes, int B, int Tx, int Ty, void *stream) {
+    if (!energies || !t_xs || !t_ys || !log_alpha || !grad_energies_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (!grad_log_alpha && !grad_gamma) return fail(ALIGNER_EINVAL, "no cotangent: grad_log_alpha and grad_gamma are both null");
+    if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
+    if (max_duration < 1) return fail(ALIGNER_EINVAL, "max_duration %d < 1", max_duration);
+    const int vt = energy_dtype == ALIGNER_DT_F32 ? 0 : energy_dtype == ALIGNER_DT_BF16 ? 1 : energy_dtype == ALIGNER_DT_F16 ? 2 : -1;
+    if (vt < 0) return fail(ALIGNER_EINVAL, "energy dtype %d not supported (F32, BF16, F16)", energy_dtype);
+    if (B == 0) return ALIGNER_OK;
+    if (B > 65535 || Tx > 65535) return fail(ALIGNER_EDOM, "grid too large");
+    if ((max_duration > Ty ? Ty : max_duration) > 65535) return fail(ALIGNER_EDOM, "max_duration %d too large", max_duration);
+    MoboBwdPlan pl;
+    const int prc = mobo_bwd_plan(B, Tx, Ty, max_duration, pl, false);
+    if (prc) return prc;
+    const MoboPlan &f = pl.f;
+    if ((long long)B * f.S > 0x7fffffffLL) return fail(ALIGNER_EDOM, "grid too large");
+    if (workspace_bytes < pl.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, pl.total);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nlds = (size_t)(MB_NCH + f.D) * 12;
+    if (nlds > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "max_duration %d needs %zu bytes of LDS", f.D, nlds);
+    {   // 1. normalisers (the search's kernel; it also refills the ring and clears the give-up words)
+        MoboParams p{};
+        p.e = energies;  p.t_xs = t_xs;  p.t_ys = t_ys;
+        p.Lw = reinterpret_cast<float *>(ws + pl.L_off);
+        p.ring = reinterpret_cast<unsigned *>(ws + pl.ring_off);
+        p.failw = reinterpret_cast<int *>(ws + pl.fail_off);
+        p.status = reinterpret_cast<int *>(ws + pl.status_off);
+        p.B = B;  p.Tx = Tx;  p.Ty = Ty;  p.D = f.D;  p.S = f.S;  p.nmax = f.nmax;
+        const dim3 grid((Ty + MB_NCH - 1) / MB_NCH, Tx, B);
+        auto launch = [&](auto kern) -> int {
+            ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), nlds));
+            hipLaunchKernelGGL(kern, grid, dim3(256), nlds, s, p, (unsigned long long)pl.ring_words);
+            ALIGNER_HIP_CHECK(hipGetLastError());
+            return ALIGNER_OK;
+        };
+        const int rc = vt == 0 ? launch(mobo_norm_kernel<0>) : vt == 1 ? launch(mobo_norm_kernel<1>) : launch(mobo_norm_kernel<2>);
+        if (rc) return rc;
+    }
+    MoboBwdParams q{energies, t_xs, t_ys, log_alpha, grad_log_alpha, grad_gamma, grad_energies_out,
+                    reinterpret_cast<float *>(ws + pl.L_off), reinterpret_cast<float *>(ws + pl.U_off),
+                    reinterpret_cast<float *>(ws + pl.Q_off), reinterpret_cast<float *>(ws + pl.G_off),
+                    reinterpret_cast<float *>(ws + pl.Y_off), reinterpret_cast<unsigned *>(ws + pl.ring_off),
+                    reinterpret_cast<int *>(ws + pl.fail_off), reinterpret_cast<unsigned *>(ws + pl.trash_off),
+                    reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, f.D, f.S, f.nmax, g_opt_mobo_start_lag,
+                    g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
+    {   // 2. u, q, G for every cell
+        if (vt == 0) hipLaunchKernelGGL(mobo_bwd_prep_kernel<0>, dim3(Tx, B), dim3(256), 0, s, q);
+        else if (vt == 1) hipLaunchKernelGGL(mobo_bwd_prep_kernel<1>, dim3(Tx, B), dim3(256), 0, s, q);
+        else hipLaunchKernelGGL(mobo_bwd_prep_kernel<2>, dim3(Tx, B), dim3(256), 0, s, q);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    {   // 3. the chain over the token rows, last to first
+        auto launch = [&](auto kern) -> int {
+            ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), pl.lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)B * f.S), dim3(pl.T), pl.lds, s, q);
+            ALIGNER_HIP_CHECK(hipGetLastError());
+            return ALIGNER_OK;
+        };
+        const int rc = pl.multi ? launch(mobo_bwd_chain_kernel<true>) : launch(mobo_bwd_chain_kernel<false>);
+        if (rc) return rc;
+    }
+    {   // 4. the gradient, every cell at once
+        const dim3 grid((Ty + MB_NCH - 1) / MB_NCH, Tx, B);
+        auto launch = [&](auto kern) -> int {
+            ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), nlds));
+            hipLaunchKernelGGL(kern, grid, dim3(256), nlds, s, q);
+            ALIGNER_HIP_CHECK(hipGetLastError());
+            return ALIGNER_OK;
+        };
+        const int rc = vt == 0 ? launch(mobo_bwd_grad_kernel<0>) : vt == 1 ? launch(mobo_bwd_grad_kernel<1>) : launch(mobo_bwd_grad_kernel<2>);
+        if (rc) return rc;
+    }
+    return ALIGNER_OK;
+}
 
 size_t aligner_boundary_search_workspace_bytes_ex(int B, int Tx, int Ty, int max_duration) {
     if (B < 0 || Tx < 1 || Ty < 1 || max_duration < 1) return 0;

@@ -63,6 +63,84 @@ def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor
     return BoundarySearch(bnd, dur, score, la, ga)
 
 
+_bwd_workspaces = _lib.StreamWorkspaces(zero=True)
+
+
+def boundary_search_backward(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int,
+                             log_alpha: torch.Tensor, grad_log_alpha: Optional[torch.Tensor] = None,
+                             grad_gamma: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d loss / d energies [B,T_text,T_mel] fp32 for a loss that reads the search's log_alpha and / or gamma:
+    `log_alpha` is what boundary_search(..., want_log_alpha=True) returned for the same energies and lengths, the
+    two `grad_*` are the loss's cotangents (at least one).  Asynchronous on the current stream."""
+    _lib.require_gpu()
+    if energies.dim() != 3 or not energies.is_cuda:
+        raise ValueError("energies must be a GPU tensor [B, T_text, T_mel]")
+    if grad_log_alpha is None and grad_gamma is None:
+        raise ValueError("boundary_search_backward needs grad_log_alpha or grad_gamma")
+    e = energies.detach()
+    if e.dtype not in _DT:
+        e = e.float()
+    e = e.contiguous()
+    B, Tx, Ty = e.shape
+    dev = e.device
+
+    def plane(t, name):
+        if t is None:
+            return None
+        if t.shape != (B, Tx, Ty) or t.device != dev:
+            raise ValueError(f"{name} must be a [B, T_text, T_mel] tensor on the energies' device")
+        return t.detach().to(torch.float32).contiguous()
+
+    la = plane(log_alpha, "log_alpha")
+    if la is None:
+        raise ValueError("log_alpha (the search's output) is required")
+    gla, gga = plane(grad_log_alpha, "grad_log_alpha"), plane(grad_gamma, "grad_gamma")
+    tx = torch.as_tensor(t_x).detach().to(device=dev, dtype=torch.int32).contiguous()
+    ty = torch.as_tensor(t_y).detach().to(device=dev, dtype=torch.int32).contiguous()
+    if tx.shape != (B,) or ty.shape != (B,):
+        raise ValueError("t_x / t_y must have one entry per utterance")
+    grad = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    if B > 0:
+        with torch.cuda.device(dev):
+            need = lib.aligner_boundary_search_backward_workspace_bytes(B, Tx, Ty, int(max_duration))
+            if need == 0:
+                need = 256
+            ws = _bwd_workspaces.get(dev, need)
+            _lib.check(lib.aligner_boundary_search_backward(
+                e.data_ptr(), _DT[e.dtype], tx.data_ptr(), ty.data_ptr(), int(max_duration), la.data_ptr(),
+                None if gla is None else gla.data_ptr(), None if gga is None else gga.data_ptr(), grad.data_ptr(),
+                ws.data_ptr(), ws.numel(), B, Tx, Ty, torch.cuda.current_stream(dev).cuda_stream))
+    return grad
+
+
+class _SoftBoundaries(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, energies, t_x, t_y, max_duration):
+        r = boundary_search(energies, t_x, t_y, max_duration, want_log_alpha=True, want_gamma=True)
+        ctx.save_for_backward(energies, r.log_alpha)
+        ctx.lengths = (t_x, t_y, int(max_duration))
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(r.boundaries, r.durations, r.map_score)
+        return r.log_alpha, r.gamma, r.boundaries, r.durations, r.map_score
+
+    @staticmethod
+    def backward(ctx, g_la, g_ga, *_):
+        energies, la = ctx.saved_tensors
+        t_x, t_y, D = ctx.lengths
+        if g_la is None and g_ga is None:
+            return None, None, None, None
+        grad = boundary_search_backward(energies, t_x, t_y, D, la, g_la, g_ga)
+        return grad.to(energies.dtype), None, None, None
+
+
+def soft_boundaries(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int) -> BoundarySearch:
+    """boundary_search() with log_alpha and gamma attached to autograd: a loss on either back-propagates into
+    `energies` through boundary_search_backward (the MAP outputs carry no gradient)."""
+    la, ga, bnd, dur, score = _SoftBoundaries.apply(energies, t_x, t_y, max_duration)
+    return BoundarySearch(bnd, dur, score, la, ga)
+
+
 def read_status(device=None) -> int:
     """ALIGNER_ST_* bits left by boundary_search() calls on `device` since the last read (blocking)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -72,7 +150,7 @@ def read_status(device=None) -> int:
     out = np.zeros(1, np.int32)
     with torch.cuda.device(device):
         torch.cuda.synchronize(device)
-        for ws in _workspaces.on_device(device):
+        for ws in list(_workspaces.on_device(device)) + list(_bwd_workspaces.on_device(device)):
             _lib.check(_lib.load().aligner_maxpath_read_status(ws.data_ptr(), out.ctypes.data,
                                                                torch.cuda.current_stream(device).cuda_stream))
             st |= int(out[0])

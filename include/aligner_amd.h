@@ -380,6 +380,31 @@ int aligner_boundary_search(const void *energies_dev, int energy_dtype,
                             void *workspace_dev, size_t workspace_bytes,
                             int B, int Tx, int Ty, void *stream);
 
+/*
+ * Gradient of the boundary search: d loss / d energies for a loss that reads log_alpha and / or gamma (what a
+ * MoBoAligner training step needs behind the soft alignment; build-defined like the search, pinned in
+ * oracle/mobo_oracle.py::boundary_search_backward to autograd over a float64 restatement of the forward pass).
+ *   energies_dev, t_xs_dev, t_ys_dev, max_duration: as given to aligner_boundary_search
+ *   log_alpha_dev       [B,Tx,Ty] fp32: that call's log_alpha_out_dev
+ *   grad_log_alpha_dev  optional [B,Tx,Ty] fp32 cotangent of log_alpha (entries where log_alpha is -inf are ignored)
+ *   grad_gamma_dev      optional [B,Tx,Ty] fp32 cotangent of gamma; at least one of the two
+ *   grad_energies_out_dev [B,Tx,Ty] fp32 (0 outside an utterance's lengths and for an utterance without a
+ *                       segmentation)
+ *   workspace_dev       aligner_boundary_search_backward_workspace_bytes(...) bytes, first 256 zeroed once (status
+ *                       word as above).  Five [B,Tx,Ty] fp32 planes and the hand-off ring.
+ * The MAP outputs (boundaries, durations, map_score) are not differentiated.  Four launches: the normalisers, the
+ * per-cell operands, the chain over the token rows from the last to the first (the search's position segments,
+ * handing their first max_duration entries to the left), the gradient of every cell.  Same limits and the same
+ * defined failure (ALIGNER_ST_INTERNAL, all-zero gradient for that utterance) as the search.
+ */
+size_t aligner_boundary_search_backward_workspace_bytes(int B, int Tx, int Ty, int max_duration);
+int aligner_boundary_search_backward(const void *energies_dev, int energy_dtype,
+                                     const int32_t *t_xs_dev, const int32_t *t_ys_dev, int max_duration,
+                                     const float *log_alpha_dev, const float *grad_log_alpha_dev,
+                                     const float *grad_gamma_dev, float *grad_energies_out_dev,
+                                     void *workspace_dev, size_t workspace_bytes,
+                                     int B, int Tx, int Ty, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

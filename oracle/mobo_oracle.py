@@ -233,3 +233,132 @@ def brute_force(e: np.ndarray, D: int):
         if lp > best or (lp == best and tuple(b[::-1]) > tuple(best_b[::-1])):
             best, best_b = lp, b
     return dict(log_alpha=log_alpha, gamma=gamma, boundaries=np.asarray(best_b, np.int32), map_score=float(best))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The gradient of the search (round 3): what a training step needs behind log_alpha / gamma.
+#
+# With u_i(k) = la_{i-1}(k) - L_i(k) and q_i(j) = e_i(j) - la_i(j) = -logsumexp_{k in [j-D, j)} u_i(k), the
+# posterior of the previous boundary is r_i(k | j) = exp(u_i(k) + q_i(j)) (it sums to one over k), and for a loss
+# with the direct cotangent G_i(j) = dl/dla_i(j) the TOTAL derivative Z_i(j) = dl/dla_i(j) follows the backward
+# ("beta") recursion over the token rows
+#     Y_i(k)   = sum_{j in (k, k+D]} Z_i(j) r_i(k | j)            mass that reaches row i from position k
+#     Z_{i-1}  = G_{i-1} + Y_i,            Z_{I-1} = G_{I-1}
+#     dl/de[i, m-1] = Z_i(m) - sum_{k in [m-D, m)} exp(e_i(m) - L_i(k)) Y_i(k)
+# (the chain is locally normalised, so the classical beta variable is identically one and gamma needs no backward
+# pass; THIS recursion is the adjoint of the alpha pass).  gamma is linear in alpha = exp(la):
+#     dgamma_i(y)/dalpha_i(j) = -[j <= y],   dgamma_{i+1}(y)/dalpha_i(j) = +[j <= y],
+# so a cotangent on gamma enters G as alpha_i(j) * sum_{y >= j} (Gamma_{i+1}(y) - Gamma_i(y)).
+# Cotangents at entries whose log_alpha is -inf are ignored.
+# ------------------------------------------------------------------------------------------------------------
+def _forward_rows(e: np.ndarray, D: int):
+    """la[i+1, j] = log P(b_i = j) (row 0: the start), L[i, k]; float64, -inf = log 0."""
+    from numpy.lib.stride_tricks import sliding_window_view as swv
+    I, J = e.shape
+    la = np.full((I + 1, J + 1), NEG)
+    la[0, 0] = 0.0
+    Ls = np.full((I, J + 1), NEG)
+    pos = np.arange(J + 1)
+    for i in range(I):
+        lo, hi = _bounds(I, J, D, i)
+        s = np.full(J + 1, NEG)
+        s[1:] = e[i]
+        feas = (pos >= lo) & (pos <= hi)
+        sm = np.where(feas, s, NEG)
+        L = np.full(J + 1, NEG)
+        L[:J] = _lse_rows(swv(np.concatenate([sm[1:], np.full(D, NEG)]), D)[:J])
+        Ls[i] = L
+        with np.errstate(invalid="ignore"):
+            u = np.where(np.isfinite(L) & np.isfinite(la[i]), la[i] - L, NEG)
+        uw = swv(np.concatenate([np.full(D, NEG), u]), D)[:J + 1]
+        idx = np.nonzero(feas)[0]
+        row = np.full(J + 1, NEG)
+        with np.errstate(invalid="ignore"):
+            row[idx] = s[idx] + _lse_rows(uw[idx])
+        la[i + 1] = np.where(np.isnan(row), NEG, row)
+    return la, Ls
+
+
+def boundary_search_backward(e: np.ndarray, D: int, grad_log_alpha=None, grad_gamma=None) -> np.ndarray:
+    """dl/de [I, J] for l = <grad_log_alpha, log_alpha> + <grad_gamma, gamma> (either may be None), float64."""
+    from numpy.lib.stride_tricks import sliding_window_view as swv
+    e = np.asarray(e, np.float64)
+    I, J = e.shape
+    if not feasible(I, J, D):
+        raise ValueError(f"infeasible: need I <= J <= I*D (I={I}, J={J}, D={D})")
+    la, Ls = _forward_rows(e, D)
+    G = np.zeros((I, J + 1))
+    if grad_log_alpha is not None:
+        g = np.asarray(grad_log_alpha, np.float64)
+        G[:, 1:] += np.where(np.isfinite(la[1:, 1:]), g, 0.0)
+    if grad_gamma is not None:
+        gg = np.concatenate([np.asarray(grad_gamma, np.float64), np.zeros((1, J))])
+        for i in range(I):
+            suf = np.cumsum((gg[i + 1] - gg[i])[::-1])[::-1]           # sum over y >= j, j = 0..J-1
+            S = np.concatenate([suf, [0.0]])
+            with np.errstate(over="ignore"):
+                G[i] += np.where(np.isfinite(la[i + 1]), np.exp(la[i + 1]) * S, 0.0)
+    grad = np.zeros((I, J))
+    pos = np.arange(J + 1)
+    Y = np.zeros(J + 1)
+    for i in range(I - 1, -1, -1):
+        lo, hi = _bounds(I, J, D, i)
+        s = np.full(J + 1, NEG)
+        s[1:] = e[i]
+        feas = (pos >= lo) & (pos <= hi) & np.isfinite(s)
+        Z = G[i] + Y
+        with np.errstate(invalid="ignore"):
+            q = np.where(feas & np.isfinite(la[i + 1]), s - la[i + 1], NEG)
+            u = np.where(np.isfinite(Ls[i]) & np.isfinite(la[i]), la[i] - Ls[i], NEG)
+        q = np.where(np.isnan(q), NEG, q)
+        # Y(k) = sum_{j = k+1 .. k+D} Z(j) exp(u(k) + q(j))
+        Zw = swv(np.concatenate([Z[1:], np.zeros(D)]), D)[:J + 1]
+        qw = swv(np.concatenate([q[1:], np.full(D, NEG)]), D)[:J + 1]
+        with np.errstate(invalid="ignore", over="ignore"):
+            ex = u[:, None] + qw
+            Y = np.where(np.isfinite(ex), Zw * np.exp(np.where(np.isfinite(ex), ex, 0.0)), 0.0).sum(axis=1)
+        # grad(m) = Z(m) - sum_{k = m-D .. m-1} exp(s(m) - L(k)) Y(k)
+        Lw = swv(np.concatenate([np.full(D, NEG), Ls[i]]), D)[:J + 1]
+        Yw = swv(np.concatenate([np.zeros(D), Y]), D)[:J + 1]
+        with np.errstate(invalid="ignore", over="ignore"):
+            ex = s[:, None] - Lw
+            ok = np.isfinite(ex) & feas[:, None]
+            flow = np.where(ok, np.exp(np.where(ok, ex, 0.0)) * Yw, 0.0).sum(axis=1)
+        grad[i] = np.where(feas, Z - flow, 0.0)[1:]
+    return grad
+
+
+def boundary_search_torch(e, D: int):
+    """Differentiable float64 torch restatement of log_alpha / gamma (finite energies only): the pin of
+    boundary_search_backward through autograd.  "log 0" is -1e30 inside; returns (log_alpha with -inf, gamma)."""
+    import torch
+    I, J = e.shape
+    NEGF = -1e30
+    dt = torch.float64
+    e = e.to(dt)
+    pos = torch.arange(J + 1)
+    la_prev = torch.full((J + 1,), NEGF, dtype=dt)
+    la_prev[0] = 0.0
+    rows = []
+    for i in range(I):
+        lo, hi = _bounds(I, J, D, i)
+        s = torch.cat([torch.full((1,), NEGF, dtype=dt), e[i]])
+        feas = (pos >= lo) & (pos <= hi)
+        sm = torch.where(feas, s, torch.full_like(s, NEGF))
+        spad = torch.cat([sm[1:], torch.full((D,), NEGF, dtype=dt)])
+        L = torch.cat([torch.logsumexp(spad.unfold(0, D, 1)[:J], dim=1), torch.full((1,), NEGF, dtype=dt)])
+        live = (L > -1e29) & (la_prev > -1e29)
+        u = torch.where(live, la_prev - L, torch.full_like(L, NEGF))
+        uw = torch.cat([torch.full((D,), NEGF, dtype=dt), u]).unfold(0, D, 1)[:J + 1]
+        lse = torch.logsumexp(uw, dim=1)
+        la = torch.where(feas & (lse > -1e29), s + lse, torch.full_like(s, NEGF))
+        rows.append(la[1:])
+        la_prev = la
+    log_alpha = torch.stack(rows)
+    alive = log_alpha > -1e29
+    alpha = torch.where(alive, torch.exp(torch.where(alive, log_alpha, torch.zeros_like(log_alpha))),
+                        torch.zeros_like(log_alpha))
+    cdf = torch.cumsum(alpha, dim=1) - alpha                            # P(b_i <= y), y = 0..J-1
+    prev = torch.cat([torch.ones((1, J), dtype=dt), cdf[:-1]])
+    gamma = prev - cdf
+    return torch.where(alive, log_alpha, torch.full_like(log_alpha, float("-inf"))), gamma, alive

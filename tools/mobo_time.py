@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import aligner_amd
 dev = torch.device("cuda:0")
 def ev(fn, it=5, warm=1):
@@ -20,3 +20,10 @@ for k, v in [a.split('=') for a in sys.argv[1:]]:
     lib.aligner_debug_set_option(k.encode(), int(v))
 for D in (16, 32, 64):
     print("D=%d: %.1f us" % (D, ev(lambda: aligner_amd.boundary_search(lp, tx, ty, D))))
+# the gradient (cotangent on gamma, the training case) on top of a search that kept log_alpha
+w = torch.randn(B, Tx, Ty, generator=g).to(dev)
+for D in (16, 32, 64):
+    r = aligner_amd.boundary_search(lp, tx, ty, D, want_log_alpha=True)
+    t_f = ev(lambda: aligner_amd.boundary_search(lp, tx, ty, D, want_gamma=True))
+    t_b = ev(lambda: aligner_amd.boundary_search_backward(lp, tx, ty, D, r.log_alpha, None, w))
+    print("D=%d: search with log_alpha + gamma %.1f us, gradient %.1f us" % (D, t_f, t_b))
