@@ -1138,24 +1138,22 @@ struct MoboBwdPlan {
     int T;
     bool multi;
     size_t lds, ring_words;
-    size_t status_off, fail_off, trash_off, L_off, U_off, Q_off, G_off, Y_off, ring_off, total;
+    size_t status_off, fail_off, trash_off, L_off, G_off, Y_off, ring_off, total;
 };
 static int mobo_bwd_plan(int B, int Tx, int Ty, int max_duration, MoboBwdPlan &pl, bool quiet) {
     const int rc = mobo_plan(B, Tx, Ty, max_duration, pl.f, quiet);
     if (rc) return rc;
     const MoboPlan &f = pl.f;
-    pl.multi = f.nmax > 1024;
-    pl.T = pl.multi ? 1024 : (f.nmax + 63) / 64 * 64;
-    pl.lds = (size_t)2 * 2 * 4 * ((size_t)f.nmax + f.D) + (pl.multi ? (size_t)4 * f.nmax : 0);      // <= the search's
+    pl.multi = f.NP != 1;                          // the search's choice: the split form or several positions per thread
+    pl.T = f.T;
+    pl.lds = f.lds;                                // (Z, q, t and the reports, or Z, q and Y: never more than the search's)
     pl.ring_words = (size_t)B * (f.S - 1) * Tx * 2 * f.D;
     const size_t cells = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
     pl.status_off = 0;
     pl.fail_off = 256;
     pl.trash_off = align_up(pl.fail_off + (size_t)B * sizeof(int), 256);
     pl.L_off = align_up(pl.trash_off + ((size_t)B * f.S * 1024 + 64) * sizeof(unsigned), 256);
-    pl.U_off = pl.L_off + cells;
-    pl.Q_off = pl.U_off + cells;
-    pl.G_off = pl.Q_off + cells;
+    pl.G_off = pl.L_off + cells;
     pl.Y_off = pl.G_off + cells;
     pl.ring_off = pl.Y_off + cells;
     pl.total = align_up(pl.ring_off + pl.ring_words * sizeof(unsigned), 256);
@@ -1216,17 +1214,15 @@ int aligner_boundary_search_backward(const void *energies, int energy_dtype, con
         const int rc = vt == 0 ? launch(mobo_norm_kernel<0>) : vt == 1 ? launch(mobo_norm_kernel<1>) : launch(mobo_norm_kernel<2>);
         if (rc) return rc;
     }
+    float *Gw = reinterpret_cast<float *>(ws + pl.G_off);
     MoboBwdParams q{energies, t_xs, t_ys, log_alpha, grad_log_alpha, grad_gamma, grad_energies_out,
-                    reinterpret_cast<float *>(ws + pl.L_off), reinterpret_cast<float *>(ws + pl.U_off),
-                    reinterpret_cast<float *>(ws + pl.Q_off), reinterpret_cast<float *>(ws + pl.G_off),
+                    reinterpret_cast<float *>(ws + pl.L_off), grad_gamma ? Gw : grad_log_alpha, Gw,
                     reinterpret_cast<float *>(ws + pl.Y_off), reinterpret_cast<unsigned *>(ws + pl.ring_off),
                     reinterpret_cast<int *>(ws + pl.fail_off), reinterpret_cast<unsigned *>(ws + pl.trash_off),
                     reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, f.D, f.S, f.nmax, g_opt_mobo_start_lag,
-                    g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
-    {   // 2. u, q, G for every cell
-        if (vt == 0) hipLaunchKernelGGL(mobo_bwd_prep_kernel<0>, dim3(Tx, B), dim3(256), 0, s, q);
-        else if (vt == 1) hipLaunchKernelGGL(mobo_bwd_prep_kernel<1>, dim3(Tx, B), dim3(256), 0, s, q);
-        else hipLaunchKernelGGL(mobo_bwd_prep_kernel<2>, dim3(Tx, B), dim3(256), 0, s, q);
+                    g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT, g_debug_stamps};
+    if (grad_gamma) {   // 2. the direct cotangent of log_alpha with the gamma term folded in
+        hipLaunchKernelGGL(mobo_bwd_cotangent_kernel, dim3(Tx, B), dim3(256), 0, s, q);
         ALIGNER_HIP_CHECK(hipGetLastError());
     }
     {   // 3. the chain over the token rows, last to first
@@ -1236,7 +1232,17 @@ int aligner_boundary_search_backward(const void *energies, int energy_dtype, con
             ALIGNER_HIP_CHECK(hipGetLastError());
             return ALIGNER_OK;
         };
-        const int rc = pl.multi ? launch(mobo_bwd_chain_kernel<true>) : launch(mobo_bwd_chain_kernel<false>);
+#define MB_BWD_LAUNCH(VT_)                                                                                             \
+    (pl.multi ? launch(mobo_bwd_chain_kernel<VT_, true>)                                                              \
+     : g_opt_mobo_bwd_general ? launch(mobo_bwd_chain_kernel<VT_, false>)                                             \
+     : g_debug_stamps ? MB_BWD_LAUNCH_H(VT_, true) : MB_BWD_LAUNCH_H(VT_, false))
+#define MB_BWD_LAUNCH_H(VT_, ST_)                                                                                     \
+    (f.H == 1 ? launch(mobo_bwd_chain_one_kernel<VT_, 1, ST_>) : f.H == 2 ? launch(mobo_bwd_chain_one_kernel<VT_, 2, ST_>) \
+                                                                           : launch(mobo_bwd_chain_one_kernel<VT_, 4, ST_>))
+        if (g_opt_mobo_bwd_general && !pl.multi) pl.T = (f.nmax + 63) / 64 * 64;      // (no helper wave, one position per thread)
+        const int rc = vt == 0 ? MB_BWD_LAUNCH(0) : vt == 1 ? MB_BWD_LAUNCH(1) : MB_BWD_LAUNCH(2);
+#undef MB_BWD_LAUNCH
+#undef MB_BWD_LAUNCH_H
         if (rc) return rc;
     }
     {   // 4. the gradient, every cell at once
