@@ -213,6 +213,52 @@ def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, exa
     assert int(ws.view(torch.int32, (wsb // 4,))[0]) == 0          # status word
 
 
+@pytest.mark.parametrize("B,Tx,Ty,D", [(2, 5, 9, 3), (2, 40, 300, 16), (1, 100, 600, 7), (2, 64, 257, 32), (3, 33, 700, 40),
+                                       (1, 6, 2600, 1300), (1, 120, 1000, 16), (1, 10, 1001, 250)])
+@pytest.mark.parametrize("general", [0, 1])
+def test_boundary_search_gradient_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, general):
+    """The gradient's kernels (normalisers, cotangent, chain in its split and its general form, per-cell gradient) with
+    exactly aligner_boundary_search_backward_workspace_bytes bytes; twice, and the two forms of the chain agree."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tx + Ty + D)
+    e = torch.randn(B, Tx, Ty, generator=g).to(dev)
+    w1, w2 = torch.randn(B, Tx, Ty, generator=g).to(dev), torch.randn(B, Tx, Ty, generator=g).to(dev)
+    tx = [Tx] + [max(-(-Ty // (2 * D)), Tx - 3 * i) for i in range(1, B)]
+    ty = [min(Ty, Tx * D)] + [min(Ty - 7 * i, tx[i] * D) for i in range(1, B)]
+    t_x = torch.tensor(tx, dtype=torch.int32, device=dev)
+    t_y = torch.tensor(ty, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    wsf = lib.aligner_boundary_search_workspace_bytes_ex(B, Tx, Ty, D)
+    wf = torch.zeros(wsf, dtype=torch.uint8, device=dev)
+    bnd = torch.empty(B, Tx, dtype=torch.int32, device=dev)
+    la = torch.empty(B, Tx, Ty, dtype=torch.float32, device=dev)
+    _lib.check(lib.aligner_boundary_search(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, bnd.data_ptr(), None,
+                                           None, la.data_ptr(), None, wf.data_ptr(), wsf, B, Tx, Ty, stream))
+    wsb = lib.aligner_boundary_search_backward_workspace_bytes(B, Tx, Ty, D)
+    assert wsb > 0
+    ws, grad = Fenced(wsb, dev), Fenced(B * Tx * Ty * 4, dev)
+    outs = []
+    try:
+        for form in (general, general, 1 - general):
+            assert lib.aligner_debug_set_option(b"mobo_bwd_general", form) == 0
+            _lib.check(lib.aligner_boundary_search_backward(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D,
+                                                            la.data_ptr(), w1.data_ptr(), w2.data_ptr(), grad.ptr, ws.ptr, wsb,
+                                                            B, Tx, Ty, stream))
+            torch.cuda.synchronize()
+            outs.append(grad.view(torch.float32, (B, Tx, Ty)).clone())
+    finally:
+        lib.aligner_debug_set_option(b"mobo_bwd_general", 0)
+    for name, f in (("workspace", ws), ("gradient", grad)):
+        assert f.intact(), f"{name}: a kernel wrote outside its buffer"
+    assert torch.equal(outs[0], outs[1])
+    scale = float(outs[0].abs().max())
+    assert scale > 0 and float((outs[0] - outs[2]).abs().max()) < 1e-4 * scale
+    assert int(ws.view(torch.int32, (wsb // 4,))[0]) == 0          # status word
+    too_small = lib.aligner_boundary_search_backward(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, la.data_ptr(),
+                                                     w1.data_ptr(), None, grad.ptr, ws.ptr, wsb - 1, B, Tx, Ty, stream)
+    assert too_small == -28                                         # ALIGNER_ENOSPC
+
+
 @pytest.mark.parametrize("B,Tx,Ty", [(2, 9, 40), (2, 200, 1000), (2, 255, 400), (1, 300, 500), (1, 600, 900)])
 def test_forward_sum_ctc_form_writes_stay_inside_their_buffers(dev, B, Tx, Ty):
     lib = _lib.load()

@@ -96,7 +96,8 @@ def _lengths(rng, B, Tx, Ty, D):
 
 def _check_grad(dev, e, tx, ty, D, use_la=True, use_ga=True, dt=torch.float32, seed=0, rtol=3e-3, only=None):
     """HIP gradient against the float64 adjoint; tolerance relative to the utterance's largest gradient entry (the HIP
-    path starts from its own fp32 log_alpha, whose absolute error grows with the depth of the chain)."""
+    path starts from its own fp32 log_alpha, whose absolute error grows with the depth of the chain); cotangents are
+    standard normal."""
     import aligner_amd
     rng = np.random.default_rng(seed)
     B, Tx, Ty = e.shape
@@ -116,10 +117,11 @@ def _check_grad(dev, e, tx, ty, D, use_la=True, use_ga=True, dt=torch.float32, s
         I, J = int(tx[b]), int(ty[b])
         want = M.boundary_search_backward(e64[b, :I, :J], D, None if g1 is None else g1[b, :I, :J].astype(np.float64),
                                           None if g2 is None else g2[b, :I, :J].astype(np.float64))
-        scale = max(np.abs(want).max(), 1e-3)
-        err = np.abs(got[b, :I, :J] - want).max() / scale
-        worst = max(worst, err)
-        assert err < rtol * (1 + I / 100), (b, err, scale)
+        # relative to the utterance's largest entry, plus the rounding of Z - flow (two O(|cotangent|) terms) itself
+        err = np.abs(got[b, :I, :J] - want).max()
+        tol = rtol * (1 + I / 100) * np.abs(want).max() + 2e-5
+        worst = max(worst, err / tol)
+        assert err < tol, (b, err, tol)
         assert np.all(got[b, I:] == 0) and np.all(got[b, :, J:] == 0), b
     return worst
 

@@ -24,7 +24,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
-    t0, bad, worst_la, worst_ga = time.time(), 0, 0.0, 0.0
+    t0, bad, worst_la, worst_ga, worst_gr = time.time(), 0, 0.0, 0.0, 0.0
     for it in range(n):
         kind = int(rng.integers(0, 7))
         if kind == 0:                                           # tiny
@@ -56,9 +56,22 @@ def main():
         tx = np.array([Tx] + [int(rng.integers(max(1, -(-Ty // (2 * D))), Tx + 1)) for _ in range(B - 1)], np.int32)
         ty = np.array([Ty] + [int(rng.integers(tx[b], min(Ty, tx[b] * D) + 1)) for b in range(1, B)], np.int32)
         ed = torch.from_numpy(e).to(dt)
-        r = aligner_amd.boundary_search(ed.to(dev), torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True)
+        try:
+            r = aligner_amd.boundary_search(ed.to(dev), torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True)
+        except aligner_amd._lib.AlignerError as ex:              # the documented LDS limit (window x positions per segment)
+            if ex.code == -33:
+                continue
+            raise
+        # the gradient for random cotangents on log_alpha, on gamma or on both
+        which = int(rng.integers(0, 3))
+        g1 = rng.standard_normal((B, Tx, Ty)).astype(np.float32) if which != 1 else None
+        g2 = rng.standard_normal((B, Tx, Ty)).astype(np.float32) if which != 0 else None
+        gr = aligner_amd.boundary_search_backward(ed.to(dev), torch.from_numpy(tx), torch.from_numpy(ty), D, r.log_alpha,
+                                                  None if g1 is None else torch.from_numpy(g1).to(dev),
+                                                  None if g2 is None else torch.from_numpy(g2).to(dev))
         torch.cuda.synchronize()
         st = mobo.read_status(dev)
+        gr = gr.cpu().numpy().astype(np.float64)
         la, ga = r.log_alpha.cpu().numpy().astype(np.float64), r.gamma.cpu().numpy().astype(np.float64)
         bnd, dur, sc = r.boundaries.cpu().numpy(), r.durations.cpu().numpy(), r.map_score.cpu().numpy()
         e64 = ed.float().numpy().astype(np.float64)
@@ -72,7 +85,16 @@ def main():
                 expect_st |= 1
                 if dur[b].any() or bnd[b].any() or np.isfinite(sc[b]):
                     ok = False; msg = f"no-segmentation utterance b={b} not zeroed"; break
+                if not np.all(np.isfinite(gr[b])):
+                    ok = False; msg = f"no-segmentation utterance b={b}: gradient not finite"; break
                 continue
+            wg = M.boundary_search_backward(e64[b, :I, :J], D, None if g1 is None else g1[b, :I, :J].astype(np.float64),
+                                            None if g2 is None else g2[b, :I, :J].astype(np.float64))
+            gtol = (3e-3 * (1 + I / 100) * np.abs(wg).max() + 2e-5) * (4.0 if dt != torch.float32 or scale > 8 else 1.0) * max(1.0, scale / 2)
+            dgr = np.abs(gr[b, :I, :J] - wg).max()
+            worst_gr = max(worst_gr, dgr / gtol)
+            if dgr > gtol or gr[b, I:].any() or gr[b, :, J:].any():
+                ok = False; msg = f"gradient b={b} which={which} err={dgr:.2e} tol={gtol:.2e}"; break
             fin = np.isfinite(want["log_alpha"])
             if not np.array_equal(np.isfinite(la[b, :I, :J]), fin):
                 ok = False; msg = f"finite pattern b={b}"; break
@@ -97,7 +119,7 @@ def main():
             bad += 1
             print(f"CASE {it} FAILED kind={kind} B={B} Tx={Tx} Ty={Ty} D={D} scale={scale} dt={dt} status={st}: {msg}", flush=True)
         if it % 10 == 9:
-            print(f"{it + 1} cases, {bad} failures, worst la/ga error as a fraction of the test tolerance {worst_la:.2f} / {worst_ga:.2f}, "
+            print(f"{it + 1} cases, {bad} failures, worst la/ga/gradient error as a fraction of the test tolerance {worst_la:.2f} / {worst_ga:.2f} / {worst_gr:.2f}, "
                   f"{time.time() - t0:.0f}s", flush=True)
     print(f"done: {n} cases, {bad} failures", flush=True)
     sys.exit(1 if bad else 0)
