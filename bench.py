@@ -561,6 +561,18 @@ def run_c5(args, world: int):
         "alignment search, durations only": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, want_path=False), it, dev), 2 * cells),
         f"boundary search, max duration {D} (norm + chain + backtrack kernels)": (event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D), it, dev), 2 * cells + 4 * cells + 2 * cells + 4 * cells + 2 * cells),
     }
+    # beside the step (a training step's extra): the search keeping log_alpha + gamma, and its gradient for a cotangent on
+    # gamma -- guarded by the property every token row has (its energies only count up to a shift: the row's gradient sums to 0)
+    soft = aligner_amd.boundary_search(lp, tx, ty, D, want_gamma=True)
+    w = torch.randn(Bc, Tx, Ty, generator=g).to(dev)
+    grad = aligner_amd.boundary_search_backward(lp, tx, ty, D, soft.log_alpha, None, w)
+    gsc = float(grad.abs().max())
+    assert mobo.read_status(dev) == 0 and bool(torch.isfinite(grad).all()) and gsc > 0
+    assert float(grad.double().sum(2).abs().max()) < 2e-3 * gsc, "boundary search gradient: a token row does not sum to zero"
+    training_extra = {
+        "boundary search keeping log_alpha + gamma": round(event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D, want_gamma=True), it, dev), 2),
+        "boundary search gradient, cotangent on gamma (norm + cotangent + chain + grad kernels)": round(event_time_us(lambda: aligner_amd.boundary_search_backward(lp, tx, ty, D, soft.log_alpha, None, w), it, dev), 2),
+    }
     dom = max(stages, key=lambda n: stages[n][0])
     gbs = stages[dom][1] / (stages[dom][0] * 1e-6) / 1e9
     ups = Bc * args.steps / elapsed
@@ -580,7 +592,8 @@ def run_c5(args, world: int):
                      "note": "boundary search bytes: energies read twice (2+2 B/cell: normalisers, chain), normalisers written and "
                              "read (4+4), durations written (2); it is bound by the dependent chain over the 500 token rows "
                              "(DESIGN 7.1), not by memory",
-                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()}},
+                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()},
+                     "not_in_the_step_us": training_extra},
         "alignment_path_matches_reference_hash_on_C5_scores": ref_ok,
     }
     if not args.no_cpu_baseline:
