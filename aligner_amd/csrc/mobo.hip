@@ -154,6 +154,30 @@ __device__ __forceinline__ void mb_bounds(int I, int J, int D, int i, int &lo, i
     lo = (lo64 > i + 1) ? (int)lo64 : i + 1;
 }
 
+// Rows [i0, i1] in which positions [a, bnd) of an utterance hold a reachable boundary (i1 < 0: none).  Both limits of a
+// row's band move up with i, so it is an interval, in closed form: a loop over the token rows here was 40 us of
+// every chain launch at 500 tokens (every workgroup ran it before its first row).
+__device__ __forceinline__ void mb_active_rows(int I, int J, int D, int a, int bnd, int &i0, int &i1) {
+    // min(hi_i, (i+1) D) >= a  <=>  i >= a - J + I - 1  and  i >= ceil(a / D) - 1
+    int lo_i = a - J + I - 1;
+    const int byreach = (a + D - 1) / D - 1;
+    lo_i = lo_i > byreach ? lo_i : byreach;
+    lo_i = lo_i > 0 ? lo_i : 0;
+    // max(i + 1, J - (I-1-i) D) < bnd  <=>  i <= bnd - 2  and  (bnd > J  or  i <= I - 2 - floor((J - bnd) / D))
+    int hi_i = I - 1 < bnd - 2 ? I - 1 : bnd - 2;
+    if (bnd <= J) {
+        const int bylo = I - 2 - (J - bnd) / D;
+        hi_i = hi_i < bylo ? hi_i : bylo;
+    }
+    if (lo_i > hi_i) {
+        i0 = I;
+        i1 = -1;
+    } else {
+        i0 = lo_i;
+        i1 = hi_i;
+    }
+}
+
 // Barrier for LDS hand-offs only: __syncthreads() also drains vmcnt, which would put the latency of the next
 // row's loads and of this row's result stores on every row.
 __device__ __forceinline__ void mb_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -631,18 +655,9 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     // this lane's part of a window: entries [w0, w1) of its D
     const int w0 = (sub * D) / H, w1 = ((sub + 1) * D) / H;
 
-    // rows [i0, i1]: the segment has a reachable position (an interval: both limits of a row move up with i)
-    int i0 = I, i1 = -1;
-    for (int i = 0; i < I; ++i) {
-        int lo, hi;
-        mb_bounds(I, J, D, i, lo, hi);
-        const long long reach = (long long)(i + 1) * D;
-        const int hi2 = hi < reach ? hi : (int)reach;
-        if (lo < bnd && hi2 >= a && lo <= hi2) {
-            i0 = i0 > i ? i : i0;
-            i1 = i;
-        }
-    }
+    // rows [i0, i1]: the segment has a reachable position
+    int i0, i1;
+    mb_active_rows(I, J, D, a, bnd, i0, i1);
     auto dead_rows = [&](int from, int to) {      // rows without a reachable position: "log 0" everywhere
         for (int i = from; i < to; ++i) {
             if (has_next && !helper)
@@ -1220,7 +1235,7 @@ int aligner_boundary_search_backward(const void *energies, int energy_dtype, con
                     reinterpret_cast<float *>(ws + pl.Y_off), reinterpret_cast<unsigned *>(ws + pl.ring_off),
                     reinterpret_cast<int *>(ws + pl.fail_off), reinterpret_cast<unsigned *>(ws + pl.trash_off),
                     reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, f.D, f.S, f.nmax, g_opt_mobo_start_lag,
-                    g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT, g_debug_stamps};
+                    g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT, g_debug_stamps, g_opt_mobo_stamp_wave};
     if (grad_gamma) {   // 2. the direct cotangent of log_alpha with the gamma term folded in
         hipLaunchKernelGGL(mobo_bwd_cotangent_kernel, dim3(Tx, B), dim3(256), 0, s, q);
         ALIGNER_HIP_CHECK(hipGetLastError());
