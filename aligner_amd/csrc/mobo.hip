@@ -576,7 +576,24 @@ __device__ __forceinline__ void mb_window_fast(const float *__restrict__ sT, con
     }
 }
 
-// The split form: one position per H lanes, everything a row needs in flight a row ahead.
+// A wave's report about a row -- (a live exponent or MB_DEADM, "an entry does not fit") -- without atomics: every lane of the
+// wave stores the same pair into the wave's own slot (one ds_write_b64, no branch), and behind the row's barrier lane l of
+// every wave reads slot l & 15 and two ballots combine them.  Two slot sets by row parity; slots of waves that do not
+// exist or do not report stay neutral.
+__device__ __forceinline__ void mb_report_put(int *sRep, int par, int wave, int wm, int nofit) {
+    int2 v;
+    v.x = wm;
+    v.y = nofit;
+    *reinterpret_cast<int2 *>(sRep + (par * 16 + wave) * 2) = v;
+}
+__device__ __forceinline__ void mb_report_get(const int *sRep, int par, int lane, int &Rn, int &slow) {
+    const int2 v = *reinterpret_cast<const int2 *>(sRep + (par * 16 + (lane & 15)) * 2);
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(v.x != MB_DEADM);
+    slow = __builtin_amdgcn_ballot_w64(v.y != 0) != 0;
+    Rn = live ? __builtin_amdgcn_readlane(v.x, __builtin_ctzll(live)) : MB_DEADM;
+}
+
+// The split form: one position per H lanes, everything a row needs in flight two rows ahead.
 //
 // What paces a row here is first of all `s_waitcnt`: loads, stores and atomics retire through ONE counter in issue
 // order, and hipcc can only emit a counted wait (leave the N youngest operations in flight) when it can prove N
@@ -631,15 +648,15 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     float *sS = reinterpret_cast<float *>(sM + 2 * W);
     float *sV = sS + 2 * W;
     float *sT = sV + 2 * W;
-    int *sStat = reinterpret_cast<int *>(sT + 2 * W);   // [3 rows in rotation][2]: largest live M, "an entry does not fit"
-    if (tid < 6) sStat[tid] = (tid & 1) ? 0 : MB_DEADM;
+    int *sRep = reinterpret_cast<int *>(sT + 2 * W);    // [row parity][16 waves][2]: the waves' reports (mb_report_put)
+    if (tid < 32) { sRep[2 * tid] = MB_DEADM; sRep[2 * tid + 1] = 0; }
     for (int h = tid; h < D; h += T) {             // positions before the utterance's start (segment 0 keeps these)
         sM[h] = MB_DEADM;  sM[W + h] = MB_DEADM;
         sS[h] = 0.f;       sS[W + h] = 0.f;
         sV[h] = MB_NEG;    sV[W + h] = MB_NEG;
         sT[h] = 0.f;       sT[W + h] = 0.f;
     }
-    mb_lds_barrier();                              // (the report slots are updated with atomics by every wave)
+    mb_lds_barrier();
     const int pi = tid / H, sub = tid - pi * H;    // H consecutive lanes per position
     const int j1 = a + pi;
     const bool mine = !helper && j1 < bnd;
@@ -678,7 +695,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     dead_rows(0, i0);
     bool gave_up = false;
     int R = 0;                                     // the row's reference for the fast sum (uniform: every wave tracks it)
-    int slot = 0;                                  // row index mod 3 (the waves' reports)
+    const int wave = tid >> 6, lane = tid & 63;
 
     if (helper) {
         // ------------------------------ the helper wave: the halo of rows i0..i1 ------------------------------
@@ -744,24 +761,18 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
 #pragma unroll 1
                     for (int h = hl + 64; h < D; h += 64) halo_entry(h, MB_FILL, MB_FILL, MB_FILL);
                 }
-                {   // the wave's report: ONE LDS atomic each (a same-address atomic per lane serialises in the LDS pipe
-                    // and the barrier's lgkmcnt(0) waits for all of them: measured 1.03 -> 1.31 ms)
+                {   // the wave's report (mb_report_put: no atomics -- a same-address atomic per lane, or even per wave,
+                    // serialises in the LDS pipe and the barrier's lgkmcnt(0) waits for it)
                     const int wm = mb_wave_max_i32(Mstat);
                     const bool wfit = __builtin_amdgcn_ballot_w64(!fits) == 0;
-                    if (hl == 0) {
-                        atomicMax(&sStat[2 * slot], wm);
-                        if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
-                    }
+                    mb_report_put(sRep, i & 1, wave, wm, wfit ? 0 : 1);
                 }
                 mb_lds_barrier();
-                const int Rn = sStat[2 * slot];
+                int Rn, slow_;
+                mb_report_get(sRep, i & 1, lane, Rn, slow_);
                 R = (Rn != MB_DEADM) ? Rn : R;
-                slot = slot == 2 ? 0 : slot + 1;
             }
-        } else {
-#pragma unroll 1
-            for (int i = i0; i <= i1; ++i) mb_lds_barrier();                        // (segment 0 has no halo)
-        }
+        }                                          // (segment 0 has no halo: the wave ends, a barrier only counts live waves)
         if (gave_up) {
             atomicOr(p.status, ALIGNER_ST_INTERNAL);
             p.failw[b] = 1;
@@ -773,19 +784,29 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     // operands of a row, all lanes, clamped addresses; pointers advance by a row
     const int je = (j1 < 1 ? 1 : (j1 > J ? J : j1)) - 1;               // frame of this lane's boundary position
     const int kl = j1 > J - 1 ? J - 1 : j1;                            // the step out of J does not exist (phase 1)
-    unsigned e_nx;
-    float L_nx;
-    auto issue = [&](int i) {
+    // The operands of a row are requested TWO rows ahead: they come from HBM (every row a new cache line per plane) and a
+    // row is about one HBM round trip -- with one row of lead some wave of the workgroup found its operands late in most
+    // rows and the others waited for it at the barrier.  Two register sets take turns (the loop is unrolled by two):
+    // shifting a queue with moves would wait for the younger set's loads, a move reads its source.
+    unsigned e_n1, e_n2;
+    float L_n1, L_n2;
+    auto issue = [&](int i, unsigned &e_o, float &L_o) {
         const size_t ro = ubase + (size_t)i * p.Ty;
-        e_nx = mb_load_raw<VT>(p.e, ro + je);
-        L_nx = p.Lw[ro + kl];
+        e_o = mb_load_raw<VT>(p.e, ro + je);
+        L_o = p.Lw[ro + kl];
     };
     // without a helper wave (an unsplit launch) nobody else fetches a halo -- and there is none: S == 1
-    issue(i0);
-    // The loop is entered in the state every later row finds: the row's operand loads followed by four stores
-    // (three ring words, one duration).  hipcc sizes a counted wait for the FEWEST operations that can follow on any
-    // path into it: without these the waits inside the loop also waited for the previous row's stores to be
+    // The loop is entered in the state every later row finds: two rows of operand loads, each followed by a row's
+    // stores (three ring words, one duration, log_alpha).  hipcc sizes a counted wait for the FEWEST operations that can
+    // follow on any path into it: without these the waits inside the loop also waited for the previous row's stores to be
     // acknowledged -- 1 200 cycles of every row.
+    issue(i0, e_n1, L_n1);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    if (WANT_LA) mb_ring_store(trash, 0u);
+    issue(i0 + 1 < I ? i0 + 1 : I - 1, e_n2, L_n2);
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
     mb_ring_store(trash, 0u);
@@ -793,13 +814,12 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     if (WANT_LA) mb_ring_store(trash, 0u);
     unsigned long long st_loop = 0;
     if (stamping) { st_loop = st_t = __builtin_amdgcn_s_memtime(); }
-#pragma unroll 1
-    for (int i = i0; i <= i1; ++i) {
+    auto do_row = [&](const int i, unsigned &e_s, float &L_s) {
         int lo, hi;
         mb_bounds(I, J, D, i, lo, hi);
-        const unsigned e_c = e_nx;
-        const float L_c = L_nx;
-        issue(i + 1 < I ? i + 1 : I - 1);
+        const unsigned e_c = e_s;
+        const float L_c = L_s;
+        issue(i + 2 < I ? i + 2 : I - 1, e_s, L_s);                   // (the set just read takes the row after next)
         const size_t ro = ubase + (size_t)i * p.Ty;
         const int bo = (i & 1) * W;
         if (stamping) { asm volatile("" :: "v"(e_c), "v"(L_c)); }
@@ -828,10 +848,7 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
                 const unsigned long long lm = __builtin_amdgcn_ballot_w64(livem);
                 const bool wfit = __builtin_amdgcn_ballot_w64(livem && !(M >= R - 100 && M <= R + 100)) == 0;
                 const int wm = lm ? __builtin_amdgcn_readlane(M, __builtin_ctzll(lm)) : MB_DEADM;
-                if ((tid & 63) == 0) {
-                    atomicMax(&sStat[2 * slot], wm);
-                    if (!wfit) atomicOr(&sStat[2 * slot + 1], 1);
-                }
+                mb_report_put(sRep, i & 1, wave, wm, wfit ? 0 : 1);
             }
             unsigned *r = publishes ? ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
             const int st = publishes ? D : 0;
@@ -845,11 +862,8 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
         MB_STAMP(3)
         // ---- phase 2: the windows [j-D, j) ----
         {
-            const int Rn = sStat[2 * slot], slow = sStat[2 * slot + 1];
-            {   // the slot of the row after next: every wave has read it (row i-1) before this row's barrier
-                const int nslot = slot == 0 ? 2 : slot - 1;         // (i + 2) % 3 when slot = i % 3
-                if (tid == 0) { sStat[2 * nslot] = MB_DEADM; sStat[2 * nslot + 1] = 0; }
-            }
+            int Rn, slow;
+            mb_report_get(sRep, i & 1, lane, Rn, slow);
             const float ev = mb_value<VT>(e_c) * MB_LOG2E;
             const bool feasible = mine && j1 >= lo && j1 <= hi;
             const int x = bo + (mine ? pi : 0) + w0;           // first entry of this lane's part
@@ -907,7 +921,12 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
             }
         }
         MB_STAMP(5)
-        slot = slot == 2 ? 0 : slot + 1;
+    };
+#pragma unroll 1
+    for (int i = i0; i <= i1; i += 2) {
+        do_row(i, e_n1, L_n1);
+        if (i + 1 > i1) break;
+        do_row(i + 1, e_n2, L_n2);
     }
     if (stamping) {
         unsigned long long *o = p.stamps + (size_t)blockIdx.x * 24;
