@@ -946,6 +946,318 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_ctc_backward_kernel(CtcPara
     }
 }
 
+// --------------------------------------------------------------------------
+// The CTC form on the systolic pipeline (T_text + 1 <= 252 / 504 rows): wave w owns rows 63w .. 63w+62, one per lane,
+// with the two states of a row (blank before the token, the token) in two registers -- their log-sums are
+// independent chains of one lane, so a frame costs about what the plain form's costs.  Only TOKEN states cross a
+// lane or a wave (B_r reads T_{r-1}; T_r reads T_{r-1}), so the forward ghost lane replays the upper wave's last token
+// state exactly as in fwdsum_forward_sys_kernel; backward, a token state reads BOTH states of the row below, which
+// the lower wave leaves per frame in a two-float ring.  Same alpha (token states) / per-(wave, frame) offsets in the
+// workspace, same numerics as the one-wave kernels above.
+// --------------------------------------------------------------------------
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    constexpr int SY_TILE = SY_TW * SY_LD;
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tin = fs_smem;                                     // [NW][2][TW][LD] scores (slot = lane)
+    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha of the token states
+    double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    double *tns = toff + SY_NW * 2 * SY_TW;                   // [TW] partial sums of the frames' normalisers
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & (SY_NW - 1);
+    const bool sweeper = wave < SY_NW;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
+    if (!(tx >= 1 && tx <= ty)) {                             // fewer frames than tokens: no labelling exists, loss = +inf
+        if (tid == 0) { p.loss[b] = -FS_NEG_INF; p.logz[b] = (double)FS_NEG_INF; }
+        if (!sweeper) for (int t = lane; t < p.NT; t += 64) offs[t] = 0.0;
+        return;
+    }
+    const int ntl = (ty + SY_TW - 1) / SY_TW;
+    const int row = 63 * w + lane - 1;                        // sweeper: lane 0 is the ghost (row 63w-1)
+    const bool ghost = lane == 0, okT = row < tx, okB = row <= tx;
+    float pT = FS_NEG, pB = (row == 0) ? 0.f : FS_NEG;        // B_0 before the first frame: log 1
+    float drift = 0.f;
+    double C = 0.0, drift_d = 0.0;
+    if (!sweeper) {
+        float vnext[SY_TW];
+        double nsd = 0.0;                                     // stager 0, lane c: the normalisers of the frames = c mod TW
+        auto stage_issue = [&](int tl) {
+            const int tc = tl < ntl ? tl : ntl - 1;
+            const int y0 = tc * SY_TW;
+#pragma unroll
+            for (int i = 0; i < SY_TW; ++i) {
+                const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
+                int rg = 63 * w + r - 1;
+                rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
+                const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+            }
+        };
+        stage_issue(0);
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+            const int tl = ph - w, ts = ph - 2 - w;
+            if (tl >= 0 && tl < ntl) {
+                float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    dst[c * SY_LD + r] = fs_in(vnext[i]);
+                }
+                if (w == 0 && lane < SY_TW) {
+                    const int y = tl * SY_TW + lane;
+                    if (y < ty) nsd += (double)q.nrm[(size_t)b * p.Ty + y];
+                    if (tl == ntl - 1) tns[lane] = nsd;       // (read by the last frame's sweeper, phases later)
+                }
+                stage_issue(tl + 1);
+            }
+            if (ts >= 0 && ts < ntl) {
+                const float *src = tout + (w * 2 + (ts & 1)) * SY_TILE;
+                const int y0 = ts * SY_TW;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    const int rg = 63 * w + r - 1;
+                    if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                }
+                if (lane < SY_TW && y0 + lane < ty) offs[y0 + lane] = toff[(w * 2 + (ts & 1)) * SY_TW + lane];
+            }
+            fs_lds_barrier();
+        }
+    } else {
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+            const int t = ph - 1 - w;
+            if (t >= 0 && t < ntl) {
+                const int y0 = t * SY_TW, buf = t & 1;
+                const float *src = tin + (w * 2 + buf) * SY_TILE + lane;
+                float *dst = tout + (w * 2 + buf) * SY_TILE + lane;
+                double *myoff = toff + (w * 2 + buf) * SY_TW;
+                const float *ring = tout + (((w ? w - 1 : 0) * 2 + buf) * SY_TILE) + 63;   // the wave above: its last row's token state
+                const double *cp = toff + ((w ? w - 1 : 0) * 2 + buf) * SY_TW;
+                double Ck = 0.0;
+                float xv[SY_TW], rgv[SY_TW];
+                double cpv[SY_TW];
+#pragma unroll
+                for (int c = 0; c < SY_TW; ++c) { xv[c] = src[c * SY_LD]; rgv[c] = ring[c * SY_LD]; cpv[c] = cp[c]; }
+                auto frames = [&](auto tail) {
+                    constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+                    for (int c = 0; c < SY_TW; ++c) {
+                        const int y = y0 + c;
+                        const float upT = fs_from_lane_below(FS_NEG, pT);
+                        const float vb = fs_lae2(pB, upT) + (q.blank2 - drift);
+                        const float vt = fs_lae3(pT, pB, upT) + (xv[c] - drift);
+                        C += drift_d;
+                        const bool in = !TAIL || y < ty;
+                        float nB = (okB && in) ? fmaxf(vb, FS_NEG) : FS_NEG;
+                        float nT = (okT && in) ? fmaxf(vt, FS_NEG) : FS_NEG;
+                        const float gh = (w != 0) ? fmaxf(rgv[c] + (float)(cpv[c] - C), FS_NEG) : FS_NEG;
+                        nT = ghost ? gh : nT;
+                        nB = ghost ? FS_NEG : nB;
+                        Ck = (lane == c) ? C : Ck;
+                        dst[c * SY_LD] = nT;
+                        pT = nT;
+                        pB = nB;
+                        if (TAIL && y == ty - 1) {                                   // uniform: Z = T_{tx-1} + B_tx
+                            const float below = fs_from_lane_below(FS_NEG, pT);
+                            if (row == tx && !ghost) {
+                                double ns = 0.0;
+                                for (int k = 0; k < SY_TW; ++k) ns += tns[k];
+                                const double lz = (double)fs_lae2(pB, below) + C;    // log2 Z of the raw scores
+                                p.logz[b] = lz;
+                                p.loss[b] = (float)(-(lz - ns) * FS_LN2);
+                            }
+                        }
+                        if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                            float m = fs_wave_max_dpp(fmaxf(pT, pB));
+                            if (m < 0.5f * FS_NEG) m = 0.f;
+                            C += (double)m;
+                            drift += m * (1.0f / FS_RB);
+                            drift_d = (double)drift;
+                            pT = fmaxf(pT - m, FS_NEG);
+                            pB = fmaxf(pB - m, FS_NEG);
+                        }
+                    }
+                };
+                if (y0 + SY_TW < ty) frames(std::false_type{});
+                else                 frames(std::true_type{});
+                if (lane < SY_TW) myoff[lane] = Ck;
+            }
+            fs_lds_barrier();
+        }
+    }
+}
+
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
+    extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+    float *tlp = fs_smem;                                     // [NW][2][TW][LD] scores (slot = lane)
+    float *tal = tlp + SY_NW * 2 * SY_TILE;                   // alpha of the token states (relative to C_w)
+    float *tgr = tal + SY_NW * 2 * SY_TILE;                   // gradient out
+    double *toff = reinterpret_cast<double *>(tgr + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    double *tdof = toff + SY_NW * 2 * SY_TW;                  // [NW][2][TW] D_w per frame
+    float2 *tg = reinterpret_cast<float2 *>(tdof + SY_NW * 2 * SY_TW);     // [NW][2][TW] (g_B, g_T) of a wave's FIRST row
+    float *tnrm = reinterpret_cast<float *>(tg + SY_NW * 2 * SY_TW);       // [NW][2][TW] n_y
+    float2 *dump = reinterpret_cast<float2 *>(tnrm + SY_NW * 2 * SY_TW);   // [NW][64] where the other lanes write
+    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
+    const bool sweeper = wave < SY_NW;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0;
+    for (int r = 0; r < p.Tx; ++r)
+        for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
+    if (!ok) return;
+    const double logz = p.logz[b];
+    const double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
+    const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
+    float gT = FS_NEG, gB = FS_NEG;                           // beta + emission of frame y+1, relative to D
+    const bool ghost = lane == 63, okT = row < tx, okB = row <= tx;
+    float drift = 0.f;
+    double D = 0.0, Dl = -logz, drift_d = 0.0;                // Dl = D - log Z
+    if (!sweeper) {
+        float vnext[SY_TW], unext[SY_TW];
+        double onext = 0.0;
+        float nnext = 0.f;
+        auto stage_issue = [&](int kl) {                      // tile counted from the end, clamped
+            const int kc = kl < ntl ? kl : ntl - 1;
+            const int y0 = (ntl - 1 - kc) * SY_TW;
+#pragma unroll
+            for (int i = 0; i < SY_TW; ++i) {
+                const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                int rg = 63 * w + r;
+                rg = rg < tx ? rg : tx - 1;
+                const int yc = y0 + c < ty ? y0 + c : ty - 1;
+                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+            }
+            const int yo = y0 + (lane & (SY_TW - 1));
+            onext = offs[yo < ty ? yo : ty - 1];
+            nnext = q.nrm[(size_t)b * p.Ty + (yo < ty ? yo : ty - 1)];
+        };
+        stage_issue(0);
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+            const int kl = ph - wr, ks = ph - 2 - wr;         // tile counted from the end
+            if (kl >= 0 && kl < ntl) {
+                const int t = ntl - 1 - kl, y0 = t * SY_TW;
+                float *dlp = tlp + (w * 2 + (kl & 1)) * SY_TILE, *dal = tal + (w * 2 + (kl & 1)) * SY_TILE;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    dlp[c * SY_LD + r] = fs_in(vnext[i]);
+                    dal[c * SY_LD + r] = unext[i];
+                }
+                if (lane < SY_TW) {
+                    toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
+                    tnrm[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? nnext : 0.f;
+                }
+                stage_issue(kl + 1);
+            }
+            if (ks >= 0 && ks < ntl) {
+                const float *src = tgr + (w * 2 + (ks & 1)) * SY_TILE;
+                const int y0 = (ntl - 1 - ks) * SY_TW;
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                    const int rg = 63 * w + r;
+                    if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                }
+            }
+            fs_lds_barrier();
+        }
+    } else {
+        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+            const int k = ph - 1 - wr;
+            if (k >= 0 && k < ntl) {
+                const int buf = k & 1, y0 = (ntl - 1 - k) * SY_TW;
+                const float *slp = tlp + (w * 2 + buf) * SY_TILE + lane, *sal = tal + (w * 2 + buf) * SY_TILE + lane;
+                float *dgr = tgr + (w * 2 + buf) * SY_TILE + lane;
+                const double *myoff = toff + (w * 2 + buf) * SY_TW;
+                const float *mynrm = tnrm + (w * 2 + buf) * SY_TW;
+                double *mydof = tdof + (w * 2 + buf) * SY_TW;
+                float2 *myg = tg + (w * 2 + buf) * SY_TW;
+                float2 *mydump = dump + w * 64 + lane;
+                const int wb = w + 1 < SY_NW ? w + 1 : w;     // the wave below: its first row's states, its D offsets
+                const float2 *ring = tg + (wb * 2 + buf) * SY_TW;
+                const double *dp = tdof + (wb * 2 + buf) * SY_TW;
+                double Dk = 0.0;
+                float xv[SY_TW], alv[SY_TW], nyv[SY_TW];
+                float2 rgv[SY_TW];
+                double cov[SY_TW], dpv[SY_TW];
+#pragma unroll
+                for (int c = 0; c < SY_TW; ++c) {
+                    xv[c] = slp[c * SY_LD]; alv[c] = sal[c * SY_LD]; rgv[c] = ring[c];
+                    cov[c] = myoff[c]; dpv[c] = dp[c]; nyv[c] = mynrm[c];
+                }
+                auto frames = [&](auto tail) {
+                    constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+                    for (int c = SY_TW - 1; c >= 0; --c) {
+                        const int y = y0 + c;
+                        if (TAIL && y >= ty) {                                       // uniform: padding frames
+                            dgr[c * SY_LD] = 0.f;
+                            continue;
+                        }
+                        const float x = xv[c], al = alv[c];
+                        const float st = (float)(cov[c] + Dl);                       // C_w[y] + D_w - log Z, uniform
+                        const float aB = fs_from_lane_above(FS_NEG, gB);             // the row below
+                        const float aT = fs_from_lane_above(FS_NEG, gT);
+                        float bT, bB;
+                        if (TAIL && y == ty - 1) {                                   // uniform branch
+                            bT = (row == tx - 1) ? 0.f : FS_NEG;
+                            bB = (row == tx) ? 0.f : FS_NEG;
+                        } else {
+                            bT = fs_lae3(gT, aB, aT);
+                            bB = fs_lae2(gB, gT);
+                        }
+                        bT = okT ? bT : FS_NEG;
+                        bB = okB ? bB : FS_NEG;
+                        const float occ = __builtin_amdgcn_exp2f(al + bT + st);      // 2^(-1e30) = 0
+                        dgr[c * SY_LD] = okT ? __builtin_amdgcn_exp2f(x - nyv[c]) - occ : 0.f;
+                        float nT = fmaxf(bT + (x - drift), FS_NEG);
+                        float nB = fmaxf(bB + (q.blank2 - drift), FS_NEG);
+                        D += drift_d;
+                        Dl += drift_d;
+                        const float cv = (float)(dpv[c] - D);
+                        const bool has = w + 1 < SY_NW;
+                        nT = ghost ? (has ? fmaxf(rgv[c].y + cv, FS_NEG) : FS_NEG) : nT;
+                        nB = ghost ? (has ? fmaxf(rgv[c].x + cv, FS_NEG) : FS_NEG) : nB;
+                        *((lane == 0) ? myg + c : mydump) = make_float2(nB, nT);
+                        Dk = (lane == c) ? D : Dk;
+                        gT = nT;
+                        gB = nB;
+                        if ((c & (FS_RB - 1)) == 0) {
+                            float m = fs_wave_max_dpp(fmaxf(gT, gB));
+                            if (m < 0.5f * FS_NEG) m = 0.f;
+                            D += (double)m;
+                            Dl += (double)m;
+                            drift += m * (1.0f / FS_RB);
+                            drift_d = (double)drift;
+                            gT = fmaxf(gT - m, FS_NEG);
+                            gB = fmaxf(gB - m, FS_NEG);
+                        }
+                    }
+                };
+                if (k != 0) frames(std::false_type{});
+                else        frames(std::true_type{});
+                if (lane < SY_TW) mydof[lane] = Dk;
+            }
+            fs_lds_barrier();
+        }
+    }
+}
+
 struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, R; };
 
 static FsLayout fs_layout(int B, int Tx, int Ty) {
@@ -1015,6 +1327,27 @@ static int fs_launch_ctc(const CtcParams &q, bool backward, hipStream_t s) {
     return ALIGNER_OK;
 }
 
+template <int SY_NW, int SY_TW>
+static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
+    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
+    const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double) + SY_TW * sizeof(double);
+    const size_t lds_b = (size_t)3 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) +
+                         (size_t)SY_NW * 2 * SY_TW * (sizeof(float2) + sizeof(float)) + (size_t)SY_NW * 64 * sizeof(float2);
+    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 255) / 256, q.f.B), dim3(256), 0, s, q);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
+    auto kb = fwdsum_ctc_backward_sys_kernel<SY_NW, SY_TW>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
+    hipLaunchKernelGGL(kf, dim3(q.f.B), dim3(SY_THREADS), lds_f, s, q);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    if (backward) {
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kb), lds_b));
+        hipLaunchKernelGGL(kb, dim3(q.f.B), dim3(SY_THREADS), lds_b, s, q);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+    }
+    return ALIGNER_OK;
+}
+
 }  // namespace aligner
 
 using namespace aligner;
@@ -1074,6 +1407,10 @@ int aligner_forward_sum_ctc_f32(const float *scores, const int32_t *t_xs, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
     // rows 0..t_x: the blank after the last token needs a row of its own
+    if (!g_opt_fwdsum_one_wave) {
+        if (Tx + 1 <= 63 * 4) return fs_launch_ctc_sys<4, 16>(q, bwd, s);
+        if (Tx + 1 <= 63 * 8) return fs_launch_ctc_sys<8, 8>(q, bwd, s);
+    }
     if (Tx + 1 <= 256) return fs_launch_ctc<4>(q, bwd, s);
     if (Tx + 1 <= 512) return fs_launch_ctc<8>(q, bwd, s);
     return fs_launch_ctc<16>(q, bwd, s);

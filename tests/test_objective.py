@@ -229,15 +229,26 @@ def test_regulate_matches_oracle_and_the_path(dev):
     assert torch.equal(tok2, al.tok)
 
 
+# T_text + 1 <= 252 / 504 rows (the blank after the last token takes one) run on the four- / eight-wave systolic kernels,
+# wider text on the one-wave kernels; `one_wave` forces the latter on the small shapes as well
 @gpu
+@pytest.mark.parametrize("one_wave", [False, True])
 @pytest.mark.parametrize("B,Tx,Ty,ragged", [(3, 7, 19, True), (2, 1, 9, False), (4, 64, 200, True), (2, 200, 1000, False),
                                              (2, 255, 600, True), (2, 256, 500, True), (1, 400, 900, True), (2, 33, 33, False),
+                                             (3, 62, 150, True), (3, 63, 150, True), (2, 125, 333, True), (2, 126, 300, False),
+                                             (2, 251, 640, True), (2, 252, 500, True), (1, 503, 1100, False), (1, 504, 700, True),
                                              (1, 600, 700, True)])
 @pytest.mark.parametrize("blank", [-1.0, -6.0])
-def test_forward_sum_ctc_form_matches_torch_ctc_loss(dev, B, Tx, Ty, ragged, blank):
+def test_forward_sum_ctc_form_matches_torch_ctc_loss(dev, request, B, Tx, Ty, ragged, blank, one_wave):
     """The published (CTC / blank) form of the forward-sum loss against torch.nn.functional.ctc_loss in float64 on the
     CPU -- an external implementation -- loss and gradient, through the C ABI, with the tolerances of the plain form."""
     import aligner_amd
+    from aligner_amd import _lib
+    if one_wave:
+        if Tx + 1 > 504:
+            pytest.skip("already the one-wave kernel")
+        _lib.check(_lib.load().aligner_debug_set_option(b"fwdsum_one_wave", 1))
+        request.addfinalizer(lambda: _lib.load().aligner_debug_set_option(b"fwdsum_one_wave", 0))
     rng = np.random.default_rng(B * 777 + Tx)
     x = _rand_logp(rng, B, Tx, Ty)                                    # log-softmax'd attention, as the OTA model feeds it
     if ragged:

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import aligner_amd
 dev = torch.device("cuda:0")
 def ev(fn, it=10, warm=2):
