@@ -675,25 +675,49 @@ struct CtcParams {
     float blank2;           // blank score, base 2
 };
 
-// n_y = log2( 2^blank + sum_{r < t_x} 2^x[r,y] ): one thread per frame, rows streamed (coalesced over frames)
+// n_y = log2( 2^blank + sum_{r < t_x} 2^x[r,y] ): 64 frames per workgroup, the rows dealt to its four waves (wave g takes
+// rows g, g+4, ...: four loads in flight per thread, a running (max, sum) pair), the four partial pairs met through LDS.
+// (One thread per frame over all rows was a chain of t_x dependent loads: 56 us at [64,200,1000], 1 TB/s.)
 __global__ __launch_bounds__(256) void ctc_colnorm_kernel(CtcParams q) {
     const FwdSumParams &p = q.f;
-    const int b = blockIdx.y, y = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float sm[4][64], ss[4][64];
+    const int b = blockIdx.y, fx = threadIdx.x & 63, g = threadIdx.x >> 6, y = blockIdx.x * 64 + fx;
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
-    if (y >= p.Ty) return;
-    float m = q.blank2, s = 1.f;
+    float m = FS_NEG, s = 0.f;
     if (y < ty) {
         const float *col = p.logp + (size_t)b * p.Tx * p.Ty + y;
-        for (int r = 0; r < tx; ++r) {
+        int r = g;
+        for (; r + 12 < tx; r += 16) {
+            const float v0 = fs_in(col[(size_t)r * p.Ty]), v1 = fs_in(col[(size_t)(r + 4) * p.Ty]);
+            const float v2 = fs_in(col[(size_t)(r + 8) * p.Ty]), v3 = fs_in(col[(size_t)(r + 12) * p.Ty]);
+            const float mn = fmaxf(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)), m);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + ((__builtin_amdgcn_exp2f(v0 - mn) + __builtin_amdgcn_exp2f(v1 - mn)) +
+                                                      (__builtin_amdgcn_exp2f(v2 - mn) + __builtin_amdgcn_exp2f(v3 - mn)));
+            m = mn;
+        }
+        for (; r < tx; r += 4) {
             const float v = fs_in(col[(size_t)r * p.Ty]);
             const float mn = fmaxf(m, v);
             s = s * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(v - mn);
             m = mn;
         }
     }
-    q.nrm[(size_t)b * p.Ty + y] = m + __builtin_amdgcn_logf(s);
+    sm[g][fx] = m;
+    ss[g][fx] = s;
+    __syncthreads();
+    if (g == 0 && y < p.Ty) {
+        float M = q.blank2, S = 1.f;                                       // the blank column
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mk = sm[k][fx], sk = ss[k][fx];
+            const float mn = fmaxf(M, mk);
+            S = S * __builtin_amdgcn_exp2f(M - mn) + sk * __builtin_amdgcn_exp2f(mk - mn);
+            M = mn;
+        }
+        q.nrm[(size_t)b * p.Ty + y] = M + __builtin_amdgcn_logf(S);
+    }
 }
 
 template <int R>
@@ -1312,7 +1336,7 @@ static int fs_launch_ctc(const CtcParams &q, bool backward, hipStream_t s) {
     constexpr int ROWS = 64 * R + 4;
     const size_t lds_f = (size_t)4 * (128 / R) * ROWS * sizeof(float) + 2 * (128 / R) * (sizeof(double) + sizeof(float));
     const size_t lds_b = (size_t)6 * (64 / R) * ROWS * sizeof(float) + 2 * (64 / R) * (sizeof(double) + sizeof(float));
-    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 255) / 256, q.f.B), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 63) / 64, q.f.B), dim3(256), 0, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
     auto kf = fwdsum_ctc_forward_kernel<R>;
     auto kb = fwdsum_ctc_backward_kernel<R>;
@@ -1333,7 +1357,7 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
     const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double) + SY_TW * sizeof(double);
     const size_t lds_b = (size_t)3 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) +
                          (size_t)SY_NW * 2 * SY_TW * (sizeof(float2) + sizeof(float)) + (size_t)SY_NW * 64 * sizeof(float2);
-    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 255) / 256, q.f.B), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 63) / 64, q.f.B), dim3(256), 0, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
     auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_ctc_backward_sys_kernel<SY_NW, SY_TW>;
