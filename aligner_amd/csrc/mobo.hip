@@ -250,14 +250,38 @@ __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned l
         return;
     }
     const int NE = MB_NCH + D;                        // staged entries
+    const int NEp = (NE + 3) & ~3;                    // (each array 16-byte aligned: the fast sums read float4s)
     int *sM = reinterpret_cast<int *>(smem);
-    float *sS = reinterpret_cast<float *>(sM + NE);
-    float *sT = sS + NE;
+    float *sS = reinterpret_cast<float *>(sM + NEp);
+    float *sT = sS + NEp;
     __shared__ int s_blockmax;
     if (tid == 0) s_blockmax = MB_DEADM;
     // entries x = 0 .. NE-1 stand for boundary positions m = k0+1+x, i.e. frames m-1
     int Mmax = MB_DEADM;
-    for (int x = tid; x < NE; x += 256) {
+    {   // the first 1 280 entries (everything when D <= 256): all of a thread's loads in flight before the first is used
+        // -- one load per loop iteration was a chain of HBM round trips, and the kernel's whole time
+        unsigned raw[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            int f = k0 + tid + 256 * it;                  // frame m - 1 of entry x = tid + 256 it
+            f = f < p.Ty ? f : p.Ty - 1;
+            raw[it] = mb_load_raw<VT>(p.e, rowoff + f);
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int x = tid + 256 * it, m = k0 + 1 + x;
+            if (x < NE) {
+                const float e2 = (m >= lo && m <= hi) ? mb_value<VT>(raw[it]) * MB_LOG2E : MB_NEG;
+                int M;
+                float s;
+                mb_encode(e2, M, s);
+                sM[x] = M;
+                sS[x] = s;
+                Mmax = Mmax > M ? Mmax : M;
+            }
+        }
+    }
+    for (int x = tid + 1280; x < NE; x += 256) {
         const int m = k0 + 1 + x;
         float e2 = MB_NEG;
         if (m >= lo && m <= hi) e2 = mb_value<VT>(mb_load_raw<VT>(p.e, rowoff + (m - 1))) * MB_LOG2E;
@@ -285,29 +309,52 @@ __global__ __launch_bounds__(256) void mobo_norm_kernel(MoboParams p, unsigned l
         if (M != MB_DEADM && M < Rb - 100) fits = false;
     }
     const int slow = __syncthreads_or(!fits);
+    // Four ADJACENT positions per thread: their windows [x, x+D) share all but three entries at either end, so the D + 3
+    // entries are read once (aligned 16-byte LDS reads) and the common part is summed once -- a quarter of the LDS
+    // traffic and of the additions of four separate windows (the kernel was bound by both: 60 us at [8,500,4000]).
+    const int xb = 4 * tid;
+    float Ls[4] = {MB_NEG, MB_NEG, MB_NEG, MB_NEG};
+    if (k0 + xb < p.Ty) {
+        if (!slow && D >= 8) {
+            const float *t = sT + xb;
+            const float4 h = *reinterpret_cast<const float4 *>(t);              // entries 0..3
+            float core = h.w;                                                     // entries 3 .. D-1: in every one of the four
+            int c = 4;
+            for (; c + 8 <= D; c += 8) {
+                const float4 a = *reinterpret_cast<const float4 *>(t + c), bq = *reinterpret_cast<const float4 *>(t + c + 4);
+                core += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
+            }
+            for (; c < D; ++c) core += t[c];
+            const float e0 = t[D], e1 = t[D + 1], e2 = t[D + 2];
+            const float acc[4] = {core + ((h.x + h.y) + h.z), core + ((h.y + h.z) + e0), core + ((h.z + e0) + e1),
+                                  core + ((e0 + e1) + e2)};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (acc[u] > 0.f) Ls[u] = (float)Rb + __builtin_amdgcn_logf(acc[u]);
+        } else if (!slow) {
 #pragma unroll 1
-    for (int q = 0; q < MB_NCH / 256; ++q) {
-        const int x0 = tid + 256 * q, k = k0 + x0;
-        if (k >= p.Ty) break;
-        float L = MB_NEG;
-        if (k < J && k >= klo && k <= khi) {
-            if (!slow) {
+            for (int u = 0; u < 4; ++u) {
                 float acc = 0.f;
-                const float *t = sT + x0;
-                int c = 0;
-                for (; c + 8 <= D; c += 8)
-                    acc += ((t[c] + t[c + 1]) + (t[c + 2] + t[c + 3])) + ((t[c + 4] + t[c + 5]) + (t[c + 6] + t[c + 7]));
-                for (; c < D; ++c) acc += t[c];
-                if (acc > 0.f) L = (float)Rb + __builtin_amdgcn_logf(acc);
-            } else {
+                for (int c = 0; c < D; ++c) acc += sT[xb + u + c];
+                if (acc > 0.f) Ls[u] = (float)Rb + __builtin_amdgcn_logf(acc);
+            }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
                 int Mw, qb;
                 float acc, best;
-                mb_window<false>(sM + x0, sS + x0, nullptr, D, Mw, acc, best, qb);
-                if (acc > 0.f) L = (float)Mw + __builtin_amdgcn_logf(acc);
+                mb_window<false>(sM + xb + u, sS + xb + u, nullptr, D, Mw, acc, best, qb);
+                if (acc > 0.f) Ls[u] = (float)Mw + __builtin_amdgcn_logf(acc);
             }
         }
-        p.Lw[rowoff + k] = L;
-        if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + xb + u;
+            if (k < p.Ty) {
+                p.Lw[rowoff + k] = (k < J && k >= klo && k <= khi) ? Ls[u] : MB_NEG;
+                if (p.log_alpha && k >= J) p.log_alpha[rowoff + k] = -__builtin_huge_valf();
+            }
+        }
     }
 }
 
@@ -1228,7 +1275,7 @@ int aligner_boundary_search_backward(const void *energies, int energy_dtype, con
     if (workspace_bytes < pl.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, pl.total);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t nlds = (size_t)(MB_NCH + f.D) * 12;
+    const size_t nlds = (size_t)(MB_NCH + f.D + 4) * 12;
     if (nlds > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "max_duration %d needs %zu bytes of LDS", f.D, nlds);
     {   // 1. normalisers (the search's kernel; it also refills the ring and clears the give-up words)
         MoboParams p{};
@@ -1336,7 +1383,7 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
                  reinterpret_cast<int *>(ws + pl.status_off), B, Tx, Ty, pl.D, pl.S, pl.nmax, pl.bstride, g_opt_mobo_start_lag, g_debug_stamps,
                  g_opt_mobo_drop_segment, g_opt_mobo_drop_segment >= 0 ? 2048 : MB_SPIN_LIMIT};
     {   // 1. normalisers (+ ring refill)
-        const size_t nlds = (size_t)(MB_NCH + pl.D) * 12;
+        const size_t nlds = (size_t)(MB_NCH + pl.D + 4) * 12;
         if (nlds > (size_t)device_lds_limit()) return fail(ALIGNER_EDOM, "max_duration %d needs %zu bytes of LDS", pl.D, nlds);
         const dim3 grid((Ty + MB_NCH - 1) / MB_NCH, Tx, B);
         auto launch = [&](auto kern) -> int {
