@@ -1,5 +1,5 @@
 import torch, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from aligner_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 def ev(fn, it=20, warm=3):
