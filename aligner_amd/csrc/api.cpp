@@ -28,6 +28,7 @@ int g_opt_mobo_drop_segment = -1;
 int g_opt_mobo_start_lag = 1;
 int g_opt_mobo_lanes = 0;
 int g_opt_mobo_bwd_general = 0;
+int g_opt_mobo_full_chain = 0;
 int g_opt_mobo_stamp_wave = 0;
 
 hipError_t ensure_dynamic_lds(const void *kernel, size_t bytes) {
@@ -106,6 +107,7 @@ int aligner_debug_set_option(const char *name, int value) {
     if (std::strcmp(name, "mobo_start_lag") == 0) { aligner::g_opt_mobo_start_lag = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_lanes") == 0) { aligner::g_opt_mobo_lanes = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_stamp_wave") == 0) { aligner::g_opt_mobo_stamp_wave = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "mobo_full_chain") == 0) { aligner::g_opt_mobo_full_chain = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_bwd_general") == 0) { aligner::g_opt_mobo_bwd_general = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_drop_segment") == 0) { aligner::g_opt_mobo_drop_segment = value; return ALIGNER_OK; }
     return aligner::fail(ALIGNER_EINVAL, "unknown option '%s'", name);

@@ -1010,6 +1010,221 @@ __global__ __launch_bounds__(1024) void mobo_chain_one_kernel(MoboParams p) {
     }
 }
 
+// The split form when only the MAP sequence is asked for (no log_alpha): the max-product chain alone.  It never reads the
+// sum-product one, so everything that serves the sums goes -- the (M, s) encoding, the fast terms and their reference,
+// the waves' reports, the exact sums, two of the three ring words, the window's additions and its logarithm: a row is a
+// subtraction, one LDS write, one ring word, a barrier, the window's maximum with its position, an addition.  Same
+// devices otherwise (helper wave, operands two rows ahead, counted waits, trash-address stores), same results bit for
+// bit (`mobo_full_chain` selects the full kernel for the comparison: tests/test_mobo.py).
+template <int VT, int H>
+__global__ __launch_bounds__(1024) void mobo_chain_map_kernel(MoboParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const bool has_helper = p.S > 1;
+    const int T = (int)blockDim.x - (has_helper ? 64 : 0);
+    const bool helper = tid >= T;
+    const int b = blockIdx.x / p.S, sg = blockIdx.x - b * p.S;
+    const int D = p.D;
+    int I = p.t_xs[b], J = p.t_ys[b];
+    I = I > p.Tx ? p.Tx : I;
+    J = J > p.Ty ? p.Ty : J;
+    const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
+    if (!ok) {
+        if (sg == 0 && tid == 0) atomicOr(p.status, ALIGNER_ST_BAD_LENGTHS);
+        return;
+    }
+    const int P = J + 1;
+    int Sb = P / D;
+    Sb = Sb < 1 ? 1 : (Sb > p.S ? p.S : Sb);
+    const int n = (P + Sb - 1) / Sb;
+    const int a = sg * n;
+    if (sg >= Sb || a >= P) return;
+    const int bnd = (a + n < P) ? a + n : P;
+    const bool has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
+    const int W = p.nmax + D;
+    float *sV = reinterpret_cast<float *>(smem);          // [2][W]: D halo entries, then the segment's positions
+    float *sSpare = sV + 2 * W;                           // where lanes without a position write (never read)
+    for (int h = tid; h < D; h += T) {                    // positions before the utterance's start (segment 0 keeps these)
+        sV[h] = MB_NEG;
+        sV[W + h] = MB_NEG;
+    }
+    mb_lds_barrier();
+    const int pi = tid / H, sub = tid - pi * H;
+    const int j1 = a + pi;
+    const bool mine = !helper && j1 < bnd;
+    const bool lead = mine && sub == 0;
+    float de = (j1 == 0) ? 0.f : MB_NEG;                  // P(b_-1 = 0) = 1
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    unsigned short *backb = p.back + (size_t)b * p.Tx * p.bstride;
+    unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;
+    // (the ring keeps the full kernel's layout [row][3][D]; only its third plane, v, is written and awaited)
+    unsigned *ring_out = p.ring + ((size_t)b * (p.S - 1) + (has_next ? sg : 0)) * (size_t)p.Tx * 3 * D + 2 * D;
+    const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D + 2 * D;
+    const int hl = tid - T;
+    const bool publishes = has_next && lead && j1 >= bnd - D;
+    const int w0 = (sub * D) / H, w1 = ((sub + 1) * D) / H;
+    int i0, i1;
+    mb_active_rows(I, J, D, a, bnd, i0, i1);
+    auto dead_rows = [&](int from, int to) {
+        if (has_next && !helper)
+            for (int i = from; i < to; ++i)
+                for (int h = tid; h < D; h += T) mb_ring_store(ring_out + (size_t)i * 3 * D + h, __builtin_bit_cast(unsigned, MB_NEG));
+    };
+    if (i1 < 0) {
+        dead_rows(0, I);
+        if (lead && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+        return;
+    }
+    dead_rows(0, i0);
+    bool gave_up = false;
+
+    if (helper) {
+        if (sg > 0) {
+            if (p.start_lag > 0) {
+                int ig = i0 + p.start_lag;
+                ig = ig > I - 1 ? I - 1 : ig;
+                const unsigned *r = ring_in + (size_t)ig * 3 * D + (hl < D ? hl : 0);
+                int spins = 0;
+                while (mb_ring_load(r) == MB_FILL && !gave_up) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > p.spin_limit) gave_up = true;
+                }
+            }
+            const bool fetches = hl < D;
+            unsigned h_nx;
+            auto issue_halo = [&](int i) { h_nx = mb_ring_load(fetches ? ring_in + (size_t)i * 3 * D + hl : trash); };
+            issue_halo(i0);
+#pragma unroll 1
+            for (int i = i0; i <= i1; ++i) {
+                const unsigned h_c = h_nx;
+                issue_halo(i + 1 < I ? i + 1 : I - 1);
+                const int bo = (i & 1) * W;
+                auto halo_entry = [&](int h, unsigned x) {
+                    if (x == MB_FILL) {                                            // not published yet: poll
+                        const unsigned *r = ring_in + (size_t)i * 3 * D + h;
+                        int spins = 0;
+                        do {
+                            __builtin_amdgcn_s_sleep(2);
+                            x = mb_ring_load(r);
+                            if (++spins > p.spin_limit) gave_up = true;
+                        } while (x == MB_FILL && !gave_up);
+                    }
+                    sV[bo + h] = (x == MB_FILL) ? MB_NEG : __builtin_bit_cast(float, x);
+                };
+                if (fetches) halo_entry(hl, h_c);
+                if (D > 64) {
+#pragma unroll 1
+                    for (int h = hl + 64; h < D; h += 64) halo_entry(h, MB_FILL);
+                }
+                mb_lds_barrier();
+            }
+        }
+        if (gave_up) {
+            atomicOr(p.status, ALIGNER_ST_INTERNAL);
+            p.failw[b] = 1;
+        }
+        return;
+    }
+
+    const int je = (j1 < 1 ? 1 : (j1 > J ? J : j1)) - 1;
+    const int kl = j1 > J - 1 ? J - 1 : j1;
+    unsigned e_n1, e_n2;
+    float L_n1, L_n2;
+    auto issue = [&](int i, unsigned &e_o, float &L_o) {
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        e_o = mb_load_raw<VT>(p.e, ro + je);
+        L_o = p.Lw[ro + kl];
+    };
+    // (entered in the state every later row finds: two rows of operand loads, each with a row's two stores behind it)
+    issue(i0, e_n1, L_n1);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    issue(i0 + 1 < I ? i0 + 1 : I - 1, e_n2, L_n2);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    auto do_row = [&](const int i, unsigned &e_s, float &L_s) {
+        int lo, hi;
+        mb_bounds(I, J, D, i, lo, hi);
+        const unsigned e_c = e_s;
+        const float L_c = L_s;
+        issue(i + 2 < I ? i + 2 : I - 1, e_s, L_s);
+        const int bo = (i & 1) * W;
+        {   // phase 1: v = delta_{i-1}(k) - L_i(k)
+            const float L = (j1 < J) ? L_c : MB_NEG;
+            float v = (L > MB_DEADF && de > MB_DEADF) ? de - L : MB_NEG;
+            v = (v > MB_DEADF) ? v : MB_NEG;
+            *(mine ? sV + bo + D + pi : sSpare) = v;
+            mb_ring_store(publishes ? ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash, __builtin_bit_cast(unsigned, v));
+        }
+        mb_lds_barrier();
+        {   // phase 2: the window [j-D, j): its largest v, among equals the largest index
+            const float ev = mb_value<VT>(e_c) * MB_LOG2E;
+            const bool feasible = mine && j1 >= lo && j1 <= hi;
+            const float *vv = sV + bo + (mine ? pi : 0) + w0;
+            const int cnt = w1 - w0;
+            float best = MB_NEG;
+            int qb = 0, c = 0;
+            for (const int r8 = cnt & 7; c < r8; ++c) {
+                const float v = vv[c];
+                if (v >= best) { best = v; qb = c; }
+            }
+#pragma unroll 1
+            for (; c < cnt; c += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = vv[c + u];
+                float vm = v[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) vm = __builtin_fmaxf(vm, v[u]);
+                int qi = 0;
+#pragma unroll
+                for (int u = 1; u < 8; ++u) qi = (v[u] == vm) ? u : qi;
+                if (vm >= best) { best = vm; qb = c + qi; }
+            }
+            qb += w0;
+#pragma unroll
+            for (int m = 1; m < H; m <<= 1) {
+                const float bo_ = mb_quad_xor_f(best, m);
+                const int qo = mb_quad_xor_i(qb, m);
+                const bool take = bo_ > best || (bo_ == best && qo > qb);
+                best = take ? bo_ : best;
+                qb = take ? qo : qb;
+            }
+            float dev = MB_NEG;
+            int dur = 0;
+            if (feasible && ev > MB_DEADF && best > MB_DEADF) {
+                dev = ev + best;
+                dur = D - qb;
+                if (!(dev > MB_DEADF)) { dev = MB_NEG; dur = 0; }
+            }
+            de = dev;
+            unsigned short *bp = lead ? backb + (size_t)i * p.bstride + j1 : reinterpret_cast<unsigned short *>(trash);
+            *bp = (unsigned short)dur;
+        }
+    };
+#pragma unroll 1
+    for (int i = i0; i <= i1; i += 2) {
+        do_row(i, e_n1, L_n1);
+        if (i + 1 > i1) break;
+        do_row(i + 1, e_n2, L_n2);
+    }
+    if (lead && j1 == J && i1 == I - 1 && p.map_score)
+        p.map_score[b] = (de > MB_DEADF) ? de * MB_LN2 : -__builtin_huge_valf();
+    if (i1 + 1 < I) {
+        // row i1+1: nothing reachable here any more, but the states of row i1 are still owed to the next segment
+        const int i = i1 + 1;
+        if (publishes) {
+            const float Lr = p.Lw[ubase + (size_t)i * p.Ty + kl];
+            const float L = (j1 < J) ? Lr : MB_NEG;
+            float v = (L > MB_DEADF && de > MB_DEADF) ? de - L : MB_NEG;
+            v = (v > MB_DEADF) ? v : MB_NEG;
+            mb_ring_store(ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)), __builtin_bit_cast(unsigned, v));
+        }
+        dead_rows(i1 + 2, I);
+        if (lead && j1 == J && p.map_score) p.map_score[b] = -__builtin_huge_valf();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 3. Backtrack of the MAP sequence: RB rows at a time.  After t steps from position j the walk is within
 //    [j - t*D, j - t], so the durations of the batch's rows over those windows are fetched in one go.
@@ -1405,7 +1620,11 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
         int rc;
 #define MB_LAUNCH_NP(VT_)                                                                               \
     (pl.NP != 1 ? launch(mobo_chain_kernel<VT_, true>)                                                  \
-     : log_alpha_out ? MB_LAUNCH_H(VT_, true) : MB_LAUNCH_H(VT_, false))
+     : log_alpha_out ? MB_LAUNCH_H(VT_, true)                                                           \
+     : (g_opt_mobo_full_chain || g_debug_stamps) ? MB_LAUNCH_H(VT_, false) : MB_LAUNCH_MAP(VT_))
+#define MB_LAUNCH_MAP(VT_)                                                                              \
+    (pl.H == 1 ? launch(mobo_chain_map_kernel<VT_, 1>) : pl.H == 2 ? launch(mobo_chain_map_kernel<VT_, 2>) \
+                                                                    : launch(mobo_chain_map_kernel<VT_, 4>))
 #define MB_LAUNCH_H(VT_, LA_)                                                                            \
     (g_debug_stamps ? MB_LAUNCH_ST(VT_, LA_, true) : MB_LAUNCH_ST(VT_, LA_, false))
 #define MB_LAUNCH_ST(VT_, LA_, ST_)                                                                      \

@@ -184,7 +184,8 @@ def test_forward_sum_prior_regulator_writes_stay_inside_their_buffers(dev, B, Tx
 @pytest.mark.parametrize("B,Tx,Ty,D", [(2, 5, 9, 3), (2, 40, 300, 16), (1, 100, 600, 7), (2, 64, 257, 32), (3, 33, 700, 40),
                                        (1, 6, 2600, 1300), (1, 120, 1000, 16)])
 @pytest.mark.parametrize("exact_ws", [False, True])
-def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, exact_ws):
+@pytest.mark.parametrize("want_la", [True, False])
+def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, exact_ws, want_la):
     """Normalisers, the segmented chain (ring, trash area, per-(token, position) durations), backtrack and gamma kernels:
     ragged lengths, one and many segments per utterance, several positions per thread; with the workspace of the
     window-independent bound and with exactly aligner_boundary_search_workspace_bytes_ex bytes."""
@@ -200,9 +201,10 @@ def test_boundary_search_writes_stay_inside_their_buffers(dev, B, Tx, Ty, D, exa
     ws, bnd, dur, sc = Fenced(wsb, dev), Fenced(B * Tx * 4, dev), Fenced(B * Tx * 4, dev), Fenced(B * 4, dev)
     la, gm = Fenced(B * Tx * Ty * 4, dev), Fenced(B * Tx * Ty * 4, dev)
     for _ in range(2):                                   # twice: the second call meets the first one's ring and counters
+        # (without log_alpha the chain runs as the max-product kernel alone)
         _lib.check(lib.aligner_boundary_search(e.data_ptr(), _lib.DT_F32, t_x.data_ptr(), t_y.data_ptr(), D, bnd.ptr, dur.ptr,
-                                               sc.ptr, la.ptr, gm.ptr, ws.ptr, wsb, B, Tx, Ty,
-                                               torch.cuda.current_stream().cuda_stream))
+                                               sc.ptr, la.ptr if want_la else None, gm.ptr if want_la else None, ws.ptr, wsb,
+                                               B, Tx, Ty, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     for name, f in (("workspace", ws), ("boundaries", bnd), ("durations", dur), ("score", sc), ("log_alpha", la), ("gamma", gm)):
         assert f.intact(), f"{name}: a kernel wrote outside its buffer"

@@ -114,6 +114,43 @@ def test_boundary_search_matches_oracle(dev, B, Tx, Ty, D):
 
 
 @gpu
+@pytest.mark.parametrize("B,Tx,Ty,D", [(3, 1, 1, 1), (2, 5, 9, 3), (4, 12, 40, 8), (3, 40, 300, 16), (2, 64, 257, 32),
+                                       (2, 30, 1100, 64), (1, 100, 600, 7), (1, 120, 1000, 16), (5, 33, 700, 40),
+                                       (2, 8, 1500, 800), (8, 500, 4000, 32), (300, 4, 20, 6)])
+def test_map_only_chain_equals_the_full_chain(dev, B, Tx, Ty, D):
+    """Without log_alpha the search runs the max-product chain alone (mobo_chain_map_kernel); the same arithmetic as the
+    max-product half of the full kernel, so boundaries, durations and the score are bit for bit the full kernel's
+    (`mobo_full_chain` forces that one), ragged batches included -- and the score is the sequence's log-probability."""
+    import aligner_amd
+    from aligner_amd import _lib, mobo
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 10 + Tx + D)
+    e = (rng.standard_normal((B, Tx, Ty)) * 2).astype(np.float32)
+    tx = np.array([Tx] + [int(rng.integers(max(1, -(-Ty // (2 * D))), Tx + 1)) for _ in range(B - 1)], np.int32)
+    ty = np.array([Ty] + [int(rng.integers(tx[b], min(Ty, tx[b] * D) + 1)) for b in range(1, B)], np.int32)
+    if Ty > Tx * D:
+        ty[0] = Tx * D
+    ed = torch.from_numpy(e).to(dev)
+    got = aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D)
+    assert lib.aligner_debug_set_option(b"mobo_full_chain", 1) == 0
+    try:
+        ref = aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D)
+        torch.cuda.synchronize()
+    finally:
+        lib.aligner_debug_set_option(b"mobo_full_chain", 0)
+    assert mobo.read_status(dev) == 0
+    assert torch.equal(got.boundaries, ref.boundaries) and torch.equal(got.durations, ref.durations)
+    assert torch.equal(got.map_score, ref.map_score)
+    dur = got.durations.cpu().numpy()
+    for b in range(min(B, 4)):
+        I, J = int(tx[b]), int(ty[b])
+        assert dur[b, :I].min() >= 1 and dur[b, :I].max() <= D and dur[b, :I].sum() == J
+        if I * J <= 200000:
+            lp = M.sequence_log_prob(e[b, :I, :J].astype(np.float64), D, got.boundaries[b, :I].cpu().numpy())
+            assert abs(float(got.map_score[b]) - lp) < 2e-3 + 2e-5 * I
+
+
+@gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_boundary_search_sixteen_bit_energies(dev, dt):
     rng = np.random.default_rng(8)
