@@ -1225,6 +1225,266 @@ __global__ __launch_bounds__(1024) void mobo_chain_map_kernel(MoboParams p) {
     }
 }
 
+// ... and the split form when only log_alpha (and gamma) is asked for -- a training step's forward pass: the sum-product
+// chain alone.  No v, no maximum and position, no durations plane, one ring word less; the window is its fast terms'
+// sum (or the exact (M, s) sum in a row that does not fit).  Bit for bit the full kernel's log_alpha.
+template <int VT, int H>
+__global__ __launch_bounds__(1024) void mobo_chain_sum_kernel(MoboParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const bool has_helper = p.S > 1;
+    const int T = (int)blockDim.x - (has_helper ? 64 : 0);
+    const bool helper = tid >= T;
+    const int b = blockIdx.x / p.S, sg = blockIdx.x - b * p.S;
+    const int D = p.D;
+    int I = p.t_xs[b], J = p.t_ys[b];
+    I = I > p.Tx ? p.Tx : I;
+    J = J > p.Ty ? p.Ty : J;
+    const bool ok = I >= 1 && J >= I && (long long)J <= (long long)I * D;
+    if (!ok) {
+        if (sg == 0 && tid == 0) atomicOr(p.status, ALIGNER_ST_BAD_LENGTHS);
+        return;
+    }
+    const int P = J + 1;
+    int Sb = P / D;
+    Sb = Sb < 1 ? 1 : (Sb > p.S ? p.S : Sb);
+    const int n = (P + Sb - 1) / Sb;
+    const int a = sg * n;
+    if (sg >= Sb || a >= P) return;
+    const int bnd = (a + n < P) ? a + n : P;
+    const bool has_next = (sg + 1 < Sb) && (a + n < P) && sg != p.drop_seg;
+    const int W = p.nmax + D;
+    int *sM = reinterpret_cast<int *>(smem);
+    float *sS = reinterpret_cast<float *>(sM + 2 * W);
+    float *sT = sS + 2 * W;
+    int *sRep = reinterpret_cast<int *>(sT + 2 * W);      // (the full kernel's fourth array is free here: room for both)
+    float *sSpare = reinterpret_cast<float *>(sRep + 64);
+    if (tid < 32) { sRep[2 * tid] = MB_DEADM; sRep[2 * tid + 1] = 0; }
+    for (int h = tid; h < D; h += T) {
+        sM[h] = MB_DEADM;  sM[W + h] = MB_DEADM;
+        sS[h] = 0.f;       sS[W + h] = 0.f;
+        sT[h] = 0.f;       sT[W + h] = 0.f;
+    }
+    mb_lds_barrier();
+    const int pi = tid / H, sub = tid - pi * H;
+    const int j1 = a + pi;
+    const bool mine = !helper && j1 < bnd;
+    const bool lead = mine && sub == 0;
+    float la = (j1 == 0) ? 0.f : MB_NEG;
+    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    unsigned *trash = p.trash + (size_t)blockIdx.x * 1024 + tid;
+    unsigned *ring_out = p.ring + ((size_t)b * (p.S - 1) + (has_next ? sg : 0)) * (size_t)p.Tx * 3 * D;
+    const unsigned *ring_in = p.ring + ((size_t)b * (p.S - 1) + (sg > 0 ? sg - 1 : 0)) * (size_t)p.Tx * 3 * D;
+    const int hl = tid - T;
+    const bool publishes = has_next && lead && j1 >= bnd - D;
+    const int w0 = (sub * D) / H, w1 = ((sub + 1) * D) / H;
+    const int wave = tid >> 6, lane = tid & 63;
+    int i0, i1;
+    mb_active_rows(I, J, D, a, bnd, i0, i1);
+    auto dead_rows = [&](int from, int to) {
+        for (int i = from; i < to; ++i) {
+            if (has_next && !helper)
+                for (int h = tid; h < D; h += T) {
+                    unsigned *r = ring_out + (size_t)i * 3 * D + h;
+                    mb_ring_store(r, __builtin_bit_cast(unsigned, (float)MB_DEADM));
+                    mb_ring_store(r + D, 0u);
+                }
+            if (lead && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+        }
+    };
+    if (i1 < 0) {
+        dead_rows(0, I);
+        return;
+    }
+    dead_rows(0, i0);
+    bool gave_up = false;
+    int R = 0;
+
+    if (helper) {
+        if (sg > 0) {
+            if (p.start_lag > 0) {
+                int ig = i0 + p.start_lag;
+                ig = ig > I - 1 ? I - 1 : ig;
+                const unsigned *r = ring_in + (size_t)ig * 3 * D + (hl < D ? hl : 0) + D;        // the row's last word
+                int spins = 0;
+                while (mb_ring_load(r) == MB_FILL && !gave_up) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > p.spin_limit) gave_up = true;
+                }
+            }
+            const bool fetches = hl < D;
+            unsigned h0_nx, h1_nx;
+            auto issue_halo = [&](int i) {
+                const unsigned *r = fetches ? ring_in + (size_t)i * 3 * D + hl : trash;
+                h0_nx = mb_ring_load(r);
+                h1_nx = mb_ring_load(r + (fetches ? D : 0));
+            };
+            issue_halo(i0);
+#pragma unroll 1
+            for (int i = i0; i <= i1; ++i) {
+                const unsigned h_c0 = h0_nx, h_c1 = h1_nx;
+                issue_halo(i + 1 < I ? i + 1 : I - 1);
+                const int bo = (i & 1) * W;
+                int Mstat = MB_DEADM;
+                bool fits = true;
+                auto halo_entry = [&](int h, unsigned x0, unsigned x1) {
+                    if (x0 == MB_FILL || x1 == MB_FILL) {
+                        const unsigned *r = ring_in + (size_t)i * 3 * D + h;
+                        int spins = 0;
+                        do {
+                            __builtin_amdgcn_s_sleep(2);
+                            x0 = mb_ring_load(r);
+                            x1 = mb_ring_load(r + D);
+                            if (++spins > p.spin_limit) gave_up = true;
+                        } while ((x0 == MB_FILL || x1 == MB_FILL) && !gave_up);
+                    }
+                    const bool bad = (x0 == MB_FILL || x1 == MB_FILL);
+                    const int M = bad ? MB_DEADM : (int)__builtin_bit_cast(float, x0);
+                    const float sv = bad ? 0.f : __builtin_bit_cast(float, x1);
+                    sM[bo + h] = M;
+                    sS[bo + h] = sv;
+                    sT[bo + h] = __builtin_ldexpf(sv, M - R);
+                    if (M != MB_DEADM) {
+                        Mstat = Mstat > M ? Mstat : M;
+                        fits = fits && M >= R - 100 && M <= R + 100;
+                    }
+                };
+                if (fetches) halo_entry(hl, h_c0, h_c1);
+                if (D > 64) {
+#pragma unroll 1
+                    for (int h = hl + 64; h < D; h += 64) halo_entry(h, MB_FILL, MB_FILL);
+                }
+                {
+                    const int wm = mb_wave_max_i32(Mstat);
+                    const bool wfit = __builtin_amdgcn_ballot_w64(!fits) == 0;
+                    mb_report_put(sRep, i & 1, wave, wm, wfit ? 0 : 1);
+                }
+                mb_lds_barrier();
+                int Rn, slow_;
+                mb_report_get(sRep, i & 1, lane, Rn, slow_);
+                R = (Rn != MB_DEADM) ? Rn : R;
+            }
+        }
+        if (gave_up) {
+            atomicOr(p.status, ALIGNER_ST_INTERNAL);
+            p.failw[b] = 1;
+        }
+        return;
+    }
+
+    const int je = (j1 < 1 ? 1 : (j1 > J ? J : j1)) - 1;
+    const int kl = j1 > J - 1 ? J - 1 : j1;
+    unsigned e_n1, e_n2;
+    float L_n1, L_n2;
+    auto issue = [&](int i, unsigned &e_o, float &L_o) {
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        e_o = mb_load_raw<VT>(p.e, ro + je);
+        L_o = p.Lw[ro + kl];
+    };
+    // (entered in the state every later row finds: two rows of operand loads, each with a row's three stores behind it)
+    issue(i0, e_n1, L_n1);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    issue(i0 + 1 < I ? i0 + 1 : I - 1, e_n2, L_n2);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    mb_ring_store(trash, 0u);
+    auto do_row = [&](const int i, unsigned &e_s, float &L_s) {
+        int lo, hi;
+        mb_bounds(I, J, D, i, lo, hi);
+        const unsigned e_c = e_s;
+        const float L_c = L_s;
+        issue(i + 2 < I ? i + 2 : I - 1, e_s, L_s);
+        const size_t ro = ubase + (size_t)i * p.Ty;
+        const int bo = (i & 1) * W;
+        {   // phase 1: u = la_{i-1}(k) - L_i(k)
+            const float L = (j1 < J) ? L_c : MB_NEG;
+            const float u = (L > MB_DEADF && la > MB_DEADF) ? la - L : MB_NEG;
+            int M;
+            float sm;
+            mb_encode(u, M, sm);
+            int *wm_ = mine ? sM + bo + D + pi : reinterpret_cast<int *>(sSpare);
+            wm_[0] = M;
+            reinterpret_cast<float *>(mine ? wm_ + 2 * W : wm_ + 1)[0] = sm;
+            reinterpret_cast<float *>(mine ? wm_ + 4 * W : wm_ + 2)[0] = __builtin_ldexpf(sm, M - R);
+            {
+                const bool livem = lead && M != MB_DEADM;
+                const unsigned long long lm = __builtin_amdgcn_ballot_w64(livem);
+                const bool wfit = __builtin_amdgcn_ballot_w64(livem && !(M >= R - 100 && M <= R + 100)) == 0;
+                const int wm = lm ? __builtin_amdgcn_readlane(M, __builtin_ctzll(lm)) : MB_DEADM;
+                mb_report_put(sRep, i & 1, wave, wm, wfit ? 0 : 1);
+            }
+            unsigned *r = publishes ? ring_out + (size_t)i * 3 * D + (j1 - (bnd - D)) : trash;
+            mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
+            mb_ring_store(r + (publishes ? D : 0), __builtin_bit_cast(unsigned, sm));
+        }
+        mb_lds_barrier();
+        {   // phase 2: the window [j-D, j)
+            int Rn, slow;
+            mb_report_get(sRep, i & 1, lane, Rn, slow);
+            const float ev = mb_value<VT>(e_c) * MB_LOG2E;
+            const bool feasible = mine && j1 >= lo && j1 <= hi;
+            const int x = bo + (mine ? pi : 0) + w0;
+            const int cnt = w1 - w0;
+            float lsum = MB_NEG;
+            if (!slow) {
+                const float *t = sT + x;
+                float acc = 0.f;
+                int c = 0;
+                for (const int r8 = cnt & 7; c < r8; ++c) acc += t[c];
+                for (; c < cnt; c += 8)
+                    acc += ((t[c] + t[c + 1]) + (t[c + 2] + t[c + 3])) + ((t[c + 4] + t[c + 5]) + (t[c + 6] + t[c + 7]));
+#pragma unroll
+                for (int m = 1; m < H; m <<= 1) acc += mb_quad_xor_f(acc, m);
+                if (acc > 0.f) lsum = (float)R + __builtin_amdgcn_logf(acc);
+            } else {
+                int Mw, qb;
+                float acc, best;
+                mb_window<false>(sM + x, sS + x, nullptr, cnt, Mw, acc, best, qb);
+#pragma unroll
+                for (int m = 1; m < H; m <<= 1) {
+                    const int Mo = mb_quad_xor_i(Mw, m);
+                    const float ao = mb_quad_xor_f(acc, m);
+                    const int Mn = Mw > Mo ? Mw : Mo;
+                    acc = __builtin_ldexpf(acc, Mw - Mn) + __builtin_ldexpf(ao, Mo - Mn);
+                    Mw = Mn;
+                }
+                if (acc > 0.f) lsum = (float)Mw + __builtin_amdgcn_logf(acc);
+            }
+            float lav = MB_NEG;
+            if (feasible && ev > MB_DEADF && lsum > MB_DEADF) lav = ev + lsum;
+            lav = (lav > MB_DEADF) ? lav : MB_NEG;
+            la = lav;
+            R = (Rn != MB_DEADM) ? Rn : R;
+            float *lp = (lead && j1 >= 1) ? p.log_alpha + ro + (j1 - 1) : reinterpret_cast<float *>(trash);
+            *lp = (lav > MB_DEADF) ? lav * MB_LN2 : -__builtin_huge_valf();
+        }
+    };
+#pragma unroll 1
+    for (int i = i0; i <= i1; i += 2) {
+        do_row(i, e_n1, L_n1);
+        if (i + 1 > i1) break;
+        do_row(i + 1, e_n2, L_n2);
+    }
+    if (i1 + 1 < I) {
+        const int i = i1 + 1;
+        if (publishes) {
+            const float Lr = p.Lw[ubase + (size_t)i * p.Ty + kl];
+            const float L = (j1 < J) ? Lr : MB_NEG;
+            const float u = (L > MB_DEADF && la > MB_DEADF) ? la - L : MB_NEG;
+            int M;
+            float sm;
+            mb_encode(u, M, sm);
+            unsigned *r = ring_out + (size_t)i * 3 * D + (j1 - (bnd - D));
+            mb_ring_store(r, __builtin_bit_cast(unsigned, (float)M));
+            mb_ring_store(r + D, __builtin_bit_cast(unsigned, sm));
+        }
+        if (lead && j1 >= 1) p.log_alpha[ubase + (size_t)i * p.Ty + (j1 - 1)] = -__builtin_huge_valf();
+        dead_rows(i1 + 2, I);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // 3. Backtrack of the MAP sequence: RB rows at a time.  After t steps from position j the walk is within
 //    [j - t*D, j - t], so the durations of the batch's rows over those windows are fetched in one go.
@@ -1575,7 +1835,10 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
                             int max_duration, int32_t *boundaries_out, int32_t *durations_out, float *map_score_out,
                             float *log_alpha_out, float *gamma_out, void *workspace, size_t workspace_bytes, int B,
                             int Tx, int Ty, void *stream) {
-    if (!energies || !t_xs || !t_ys || !boundaries_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (!energies || !t_xs || !t_ys || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (!boundaries_out && !log_alpha_out) return fail(ALIGNER_EINVAL, "nothing asked for: boundaries_out and log_alpha_out are both null");
+    if (!boundaries_out && (durations_out || map_score_out))
+        return fail(ALIGNER_EINVAL, "durations / map_score need boundaries_out (the MAP sequence is searched or it is not)");
     if (B < 0 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d Tx=%d Ty=%d", B, Tx, Ty);
     if (max_duration < 1) return fail(ALIGNER_EINVAL, "max_duration %d < 1", max_duration);
     const int vt = energy_dtype == ALIGNER_DT_F32 ? 0 : energy_dtype == ALIGNER_DT_BF16 ? 1 : energy_dtype == ALIGNER_DT_F16 ? 2 : -1;
@@ -1620,8 +1883,12 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
         int rc;
 #define MB_LAUNCH_NP(VT_)                                                                               \
     (pl.NP != 1 ? launch(mobo_chain_kernel<VT_, true>)                                                  \
+     : (!boundaries_out && !g_opt_mobo_full_chain && !g_debug_stamps) ? MB_LAUNCH_SUM(VT_)              \
      : log_alpha_out ? MB_LAUNCH_H(VT_, true)                                                           \
      : (g_opt_mobo_full_chain || g_debug_stamps) ? MB_LAUNCH_H(VT_, false) : MB_LAUNCH_MAP(VT_))
+#define MB_LAUNCH_SUM(VT_)                                                                              \
+    (pl.H == 1 ? launch(mobo_chain_sum_kernel<VT_, 1>) : pl.H == 2 ? launch(mobo_chain_sum_kernel<VT_, 2>) \
+                                                                    : launch(mobo_chain_sum_kernel<VT_, 4>))
 #define MB_LAUNCH_MAP(VT_)                                                                              \
     (pl.H == 1 ? launch(mobo_chain_map_kernel<VT_, 1>) : pl.H == 2 ? launch(mobo_chain_map_kernel<VT_, 2>) \
                                                                     : launch(mobo_chain_map_kernel<VT_, 4>))
@@ -1633,7 +1900,7 @@ int aligner_boundary_search(const void *energies, int energy_dtype, const int32_
         rc = vt == 0 ? MB_LAUNCH_NP(0) : vt == 1 ? MB_LAUNCH_NP(1) : MB_LAUNCH_NP(2);
         if (rc) return rc;
     }
-    {   // 3. the MAP sequence
+    if (boundaries_out) {   // 3. the MAP sequence
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(mobo_backtrack_kernel), pl.bt_lds));
         hipLaunchKernelGGL(mobo_backtrack_kernel, dim3(B), dim3(256), pl.bt_lds, s, p, pl.RB);
         ALIGNER_HIP_CHECK(hipGetLastError());

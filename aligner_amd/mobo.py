@@ -19,16 +19,19 @@ _workspaces = _lib.StreamWorkspaces(zero=True)
 
 
 class BoundarySearch(NamedTuple):
-    boundaries: torch.Tensor              # [B,Tx] int32: end boundary b_i of every token (MAP sequence)
-    durations: torch.Tensor               # [B,Tx] int32
-    map_score: torch.Tensor               # [B] fp32: log-probability of that sequence
+    boundaries: Optional[torch.Tensor]    # [B,Tx] int32: end boundary b_i of every token (MAP sequence); None without want_map
+    durations: Optional[torch.Tensor]     # [B,Tx] int32
+    map_score: Optional[torch.Tensor]     # [B] fp32: log-probability of that sequence
     log_alpha: Optional[torch.Tensor]     # [B,Tx,Ty] fp32: log P(b_i = j) at [i, j-1]
     gamma: Optional[torch.Tensor]         # [B,Tx,Ty] fp32: soft alignment P(b_{i-1} <= y < b_i)
 
 
 def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int,
-                    want_log_alpha: bool = False, want_gamma: bool = False) -> BoundarySearch:
-    """energies [B,T_text,T_mel] (fp32 / bf16 / fp16, GPU), lengths [B].  Asynchronous on the current stream."""
+                    want_log_alpha: bool = False, want_gamma: bool = False, want_map: bool = True) -> BoundarySearch:
+    """energies [B,T_text,T_mel] (fp32 / bf16 / fp16, GPU), lengths [B].  Asynchronous on the current stream.
+
+    The library runs only the chain that is asked for: the max-product one (MAP boundaries / durations / score), the
+    sum-product one (log_alpha, gamma -- `want_map=False`: a training step's forward pass), or both in one kernel."""
     _lib.require_gpu()
     if energies.dim() != 3 or not energies.is_cuda:
         raise ValueError("energies must be a GPU tensor [B, T_text, T_mel]")
@@ -43,9 +46,11 @@ def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor
     if tx.shape != (B,) or ty.shape != (B,):
         raise ValueError("t_x / t_y must have one entry per utterance")
     want_log_alpha = want_log_alpha or want_gamma
-    bnd = torch.empty((B, Tx), dtype=torch.int32, device=dev)
-    dur = torch.empty((B, Tx), dtype=torch.int32, device=dev)
-    score = torch.empty((B,), dtype=torch.float32, device=dev)
+    if not want_map and not want_log_alpha:
+        raise ValueError("boundary_search: nothing asked for (want_map, want_log_alpha and want_gamma are all False)")
+    bnd = torch.empty((B, Tx), dtype=torch.int32, device=dev) if want_map else None
+    dur = torch.empty((B, Tx), dtype=torch.int32, device=dev) if want_map else None
+    score = torch.empty((B,), dtype=torch.float32, device=dev) if want_map else None
     la = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_log_alpha else None
     ga = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_gamma else None
     lib = _lib.load()
@@ -56,8 +61,9 @@ def boundary_search(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor
                 need = 256
             ws = _workspaces.get(dev, need)
             _lib.check(lib.aligner_boundary_search(
-                e.data_ptr(), _DT[e.dtype], tx.data_ptr(), ty.data_ptr(), int(max_duration), bnd.data_ptr(),
-                dur.data_ptr(), score.data_ptr(), None if la is None else la.data_ptr(),
+                e.data_ptr(), _DT[e.dtype], tx.data_ptr(), ty.data_ptr(), int(max_duration),
+                None if bnd is None else bnd.data_ptr(), None if dur is None else dur.data_ptr(),
+                None if score is None else score.data_ptr(), None if la is None else la.data_ptr(),
                 None if ga is None else ga.data_ptr(), ws.data_ptr(), ws.numel(), B, Tx, Ty,
                 torch.cuda.current_stream(dev).cuda_stream))
     return BoundarySearch(bnd, dur, score, la, ga)
@@ -116,11 +122,13 @@ def boundary_search_backward(energies: torch.Tensor, t_x: torch.Tensor, t_y: tor
 
 class _SoftBoundaries(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, energies, t_x, t_y, max_duration):
-        r = boundary_search(energies, t_x, t_y, max_duration, want_log_alpha=True, want_gamma=True)
+    def forward(ctx, energies, t_x, t_y, max_duration, want_map):
+        r = boundary_search(energies, t_x, t_y, max_duration, want_log_alpha=True, want_gamma=True, want_map=want_map)
         ctx.save_for_backward(energies, r.log_alpha)
         ctx.lengths = (t_x, t_y, int(max_duration))
         ctx.set_materialize_grads(False)
+        if not want_map:
+            return r.log_alpha, r.gamma
         ctx.mark_non_differentiable(r.boundaries, r.durations, r.map_score)
         return r.log_alpha, r.gamma, r.boundaries, r.durations, r.map_score
 
@@ -129,15 +137,20 @@ class _SoftBoundaries(torch.autograd.Function):
         energies, la = ctx.saved_tensors
         t_x, t_y, D = ctx.lengths
         if g_la is None and g_ga is None:
-            return None, None, None, None
+            return None, None, None, None, None
         grad = boundary_search_backward(energies, t_x, t_y, D, la, g_la, g_ga)
-        return grad.to(energies.dtype), None, None, None
+        return grad.to(energies.dtype), None, None, None, None
 
 
-def soft_boundaries(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int) -> BoundarySearch:
+def soft_boundaries(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, max_duration: int,
+                    want_map: bool = True) -> BoundarySearch:
     """boundary_search() with log_alpha and gamma attached to autograd: a loss on either back-propagates into
-    `energies` through boundary_search_backward (the MAP outputs carry no gradient)."""
-    la, ga, bnd, dur, score = _SoftBoundaries.apply(energies, t_x, t_y, max_duration)
+    `energies` through boundary_search_backward (the MAP outputs carry no gradient; `want_map=False` leaves them out
+    and the forward pass runs the sum-product chain alone)."""
+    out = _SoftBoundaries.apply(energies, t_x, t_y, max_duration, want_map)
+    if not want_map:
+        return BoundarySearch(None, None, None, out[0], out[1])
+    la, ga, bnd, dur, score = out
     return BoundarySearch(bnd, dur, score, la, ga)
 
 

@@ -559,7 +559,7 @@ def run_c5(args, world: int):
         "similarity, bf16 log-probs (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16), it, dev), 4 * Bc * Ca * (Tx + Ty) + 2 * cells),
         "alignment search on bf16 + int32 dense path (maxpath_pipelined_kernel x2 CUs + expand)": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, path_dtype=torch.int32), it, dev), 2 * cells + 4 * cells),
         "alignment search, durations only": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, want_path=False), it, dev), 2 * cells),
-        f"boundary search, max duration {D} (norm + chain + backtrack kernels)": (event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D), it, dev), 2 * cells + 4 * cells + 2 * cells + 4 * cells + 2 * cells),
+        f"boundary search, max duration {D} (norm + max-product chain + backtrack kernels)": (event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D), it, dev), 2 * cells + 4 * cells + 2 * cells + 4 * cells + 2 * cells),
     }
     # beside the step (a training step's extra): the search keeping log_alpha + gamma, and its gradient for a cotangent on
     # gamma -- guarded by the property every token row has (its energies only count up to a shift: the row's gradient sums to 0)
@@ -571,6 +571,7 @@ def run_c5(args, world: int):
     assert float(grad.double().sum(2).abs().max()) < 2e-3 * gsc, "boundary search gradient: a token row does not sum to zero"
     training_extra = {
         "boundary search keeping log_alpha + gamma": round(event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D, want_gamma=True), it, dev), 2),
+        "boundary search, log_alpha + gamma without the MAP sequence (a training step's forward pass)": round(event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D, want_gamma=True, want_map=False), it, dev), 2),
         "boundary search gradient, cotangent on gamma (norm + cotangent + chain + grad kernels)": round(event_time_us(lambda: aligner_amd.boundary_search_backward(lp, tx, ty, D, soft.log_alpha, None, w), it, dev), 2),
     }
     dom = max(stages, key=lambda n: stages[n][0])

@@ -151,6 +151,33 @@ def test_map_only_chain_equals_the_full_chain(dev, B, Tx, Ty, D):
 
 
 @gpu
+@pytest.mark.parametrize("B,Tx,Ty,D", [(3, 1, 1, 1), (2, 5, 9, 3), (4, 12, 40, 8), (3, 40, 300, 16), (2, 64, 257, 32),
+                                       (2, 30, 1100, 64), (1, 100, 600, 7), (1, 120, 1000, 16), (5, 33, 700, 40),
+                                       (2, 8, 1500, 800), (1, 6, 2600, 1300), (300, 4, 20, 6)])
+@pytest.mark.parametrize("scale", [2.0, 30.0])
+def test_sum_only_chain_equals_the_full_chain(dev, B, Tx, Ty, D, scale):
+    """want_map=False runs the sum-product chain alone (mobo_chain_sum_kernel): log_alpha and gamma bit for bit the full
+    kernel's, also where rows take the exact sums (energies of +-60 nats), and no MAP output is touched."""
+    import aligner_amd
+    from aligner_amd import mobo
+    rng = np.random.default_rng(B * 10 + Tx + D)
+    e = (rng.standard_normal((B, Tx, Ty)) * scale).astype(np.float32)
+    tx = np.array([Tx] + [int(rng.integers(max(1, -(-Ty // (2 * D))), Tx + 1)) for _ in range(B - 1)], np.int32)
+    ty = np.array([Ty] + [int(rng.integers(tx[b], min(Ty, tx[b] * D) + 1)) for b in range(1, B)], np.int32)
+    if Ty > Tx * D:
+        ty[0] = Tx * D
+    ed = torch.from_numpy(e).to(dev)
+    full = aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True)
+    only = aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True, want_map=False)
+    torch.cuda.synchronize()
+    assert mobo.read_status(dev) == 0
+    assert only.boundaries is None and only.durations is None and only.map_score is None
+    assert torch.equal(only.log_alpha, full.log_alpha) and torch.equal(only.gamma, full.gamma)
+    with pytest.raises(ValueError):
+        aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D, want_map=False)
+
+
+@gpu
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_boundary_search_sixteen_bit_energies(dev, dt):
     rng = np.random.default_rng(8)

@@ -212,6 +212,13 @@ def test_soft_boundaries_backpropagates_through_autograd(dev):
         assert np.abs(got[b, :I, :J] - want).max() < 3e-3 * np.abs(want).max(), b
     plain = aligner_amd.boundary_search(ed.detach(), torch.from_numpy(tx), torch.from_numpy(ty), D, want_gamma=True)
     assert torch.equal(plain.gamma, r.gamma.detach()) and torch.equal(plain.boundaries, r.boundaries)
+    # the training form: no MAP outputs, the forward pass on the sum-product chain alone -- the same gradient
+    ed2 = torch.from_numpy(e).to(dev).requires_grad_(True)
+    r2 = aligner_amd.soft_boundaries(ed2, torch.from_numpy(tx), torch.from_numpy(ty), D, want_map=False)
+    assert r2.boundaries is None and torch.equal(r2.gamma.detach(), r.gamma.detach())
+    (r2.gamma * torch.from_numpy(w).to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(ed2.grad, ed.grad)
 
 
 @gpu
