@@ -25,7 +25,7 @@ static int env_flag(const char *name) { const char *e = getenv(name); return e &
 int g_opt_fwdsum_one_wave = env_flag("ALIGNER_FWDSUM_ONE_WAVE");
 int g_opt_softattn_exact = env_flag("ALIGNER_SOFTATTN_EXACT");
 int g_opt_mobo_drop_segment = -1;
-int g_opt_mobo_start_lag = 1;
+int g_opt_mobo_start_lag = 0;
 int g_opt_mobo_lanes = 0;
 int g_opt_mobo_bwd_general = 0;
 int g_opt_mobo_full_chain = 0;

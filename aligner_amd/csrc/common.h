@@ -44,7 +44,7 @@ int device_cu_count();                // compute units of the current device (ca
 // development aid shared by the kernel files (aligner_debug_set_stamps)
 extern unsigned long long *g_debug_stamps;
 extern int g_opt_softattn_exact;       // "softattn_exact": always the exact-product similarity kernel
-extern int g_opt_mobo_start_lag;       // "mobo_start_lag": rows a position segment lets its predecessor get ahead (default 1)
+extern int g_opt_mobo_start_lag;       // "mobo_start_lag": rows a position segment lets its predecessor get ahead before it starts (default 0)
 extern int g_opt_mobo_stamp_wave;      // "mobo_stamp_wave": development, the wave whose first lane takes the gradient chain's stamps
 extern int g_opt_mobo_full_chain;      // "mobo_full_chain": testing, the search without log_alpha on the full (sum + max) chain kernel
 extern int g_opt_mobo_bwd_general;     // "mobo_bwd_general": testing, the gradient's chain in its general (one exp2 per term) form

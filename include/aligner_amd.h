@@ -215,7 +215,7 @@ void aligner_debug_set_stamps(void *stamps_dev);
  * kernels, "softattn_exact" the exact-product similarity kernel; "mobo_drop_segment" (a segment index, -1 = off)
  * makes that position segment of every utterance withhold its rows from the next one, which then gives up after a
  * short wait: the test of the boundary search's defined failure; "mobo_start_lag" (rows a position segment lets the
- * one before it get ahead, default 1) and "mobo_lanes" (lanes per position of the split form: 1, 2, 4; 0 = the plan's
+ * one before it get ahead before it starts, default 0) and "mobo_lanes" (lanes per position of the split form: 1, 2, 4; 0 = the plan's
  * choice) are the boundary search's measurement knobs (tools/mobo_time.py).  ALIGNER_EINVAL for an unknown name. */
 int aligner_debug_set_option(const char *name, int value);
 
