@@ -55,6 +55,7 @@ struct SoftAttnParams {
     float temperature;
     int sim;
     int out16;              // logp is written as bf16 (round to nearest even)
+    int pair;               // row-group form on a small batch: two waves share a 32-frame strip, each half the row tiles
 };
 
 constexpr int SA_WAVES = 8;                       // waves per workgroup: 8 x 32 = 256 mel frames share one staged text operand
@@ -323,7 +324,12 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     // 1-D grid of NQ frame ranges x B utterances.  Workgroups are dealt round-robin over the 8 XCDs
     // (observed, speed only): keep the NQ workgroups that re-read one utterance's text operand on the
     // same XCD so its L2 fetches that operand once instead of once per XCD.
-    const int NQ = (p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES);
+    // (row-group form, p.pair: the workgroup covers 128 frames, waves w and w + 4 share strip w and take the even / odd
+    // row tiles of every group -- a strip of long text is a long serial job of ONE wave otherwise, and a small batch
+    // leaves the chip's other SIMDs idle meanwhile)
+    const bool pair = MULTI && p.pair;
+    const int swv = pair ? SA_WAVES / 2 : SA_WAVES;               // strips per workgroup
+    const int NQ = (p.Ty + 32 * swv - 1) / (32 * swv);
     int b, fq;
     if ((p.B & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
         b = blockIdx.x / NQ;
         fq = blockIdx.x % NQ;
     }
-    const int col = fq * (32 * SA_WAVES) + wave * 32 + (lane & 31);
+    const int col = fq * (32 * swv) + (pair ? (wave & 3) : wave) * 32 + (lane & 31);
     const bool col_ok = col < p.Ty;
     int tx = p.Tx;
     if (p.t_xs) {
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             __syncthreads();
             stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
-            for (int r = 0; r < G; ++r) {
+            for (int r = pair ? (wave >> 2) : 0; r < G; r += pair ? 2 : 1) {
                 float lg[16];
                 tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
                                 row0 + 32 * r + 4 * half, tx, lane);
@@ -659,6 +665,17 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
                 }
             }
         }
+        if (pair) {                                   // the strip's other wave: its running (max, sum) through LDS
+            __syncthreads();                          // (the last group's fragments are read)
+            float2 *sx = reinterpret_cast<float2 *>(Ahi);
+            sx[threadIdx.x] = make_float2(m_run, l_run);
+            __syncthreads();
+            const float2 o = sx[threadIdx.x ^ 256];
+            const float m_all = fmaxf(m_run, o.x);
+            const float m_fin = (m_all == NEG_INF_F) ? 0.f : m_all;
+            l_run = (m_run == NEG_INF_F ? 0.f : l_run * __expf(m_run - m_fin)) + (o.x == NEG_INF_F ? 0.f : o.y * __expf(o.x - m_fin));
+            m_run = m_all;
+        }
         float lse;
         {
             const float m_o = __shfl_xor(m_run, 32), l_o = __shfl_xor(l_run, 32);
@@ -673,7 +690,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             __syncthreads();
             stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
-            for (int r = 0; r < G; ++r) {
+            for (int r = pair ? (wave >> 2) : 0; r < G; r += pair ? 2 : 1) {
                 float lg[16];
                 const int i_lane = row0 + 32 * r + 4 * half;
                 tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
@@ -1434,8 +1451,12 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
     const size_t lds = (size_t)2 * G * KS * 64 * sizeof(uint4) + (size_t)G * 32 * sizeof(float);
     auto kern = softattn_kernel<KS, G, MULTI>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
-    dim3 grid((unsigned)((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES)) * (unsigned)p.B), block(SA_THREADS);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+    SoftAttnParams q = p;
+    q.pair = (MULTI && !g_opt_softattn_no_pair && (long long)((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES)) * p.B < device_cu_count() &&
+              p.Ty > 128) ? 1 : 0;
+    const int swv = q.pair ? SA_WAVES / 2 : SA_WAVES;
+    dim3 grid((unsigned)((p.Ty + 32 * swv - 1) / (32 * swv)) * (unsigned)p.B), block(SA_THREADS);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }

@@ -50,6 +50,35 @@ def test_logp_matches_oracle(dev, B, C, Tx, Ty, sim):
     assert torch.allclose(soft.sum(1).cpu(), torch.ones(B, Ty), atol=1e-4)
 
 
+@pytest.mark.parametrize("B,C,Tx,Ty,sim,prior", [(2, 80, 300, 700, "l2", False), (1, 80, 500, 1000, "l2", True), (3, 80, 230, 130, "dot", False),
+                                                  (2, 128, 260, 257, "l2", False), (1, 256, 150, 400, "l2", True), (8, 80, 500, 1030, "l2", False)])
+def test_row_group_form_with_two_waves_per_strip(dev, request, B, C, Tx, Ty, sim, prior):
+    """Long text on a small batch: the row-group form gives every 32-frame strip to TWO waves (even / odd row tiles, their
+    running maxima and sums met through LDS) while one wave per strip would leave SIMDs idle.  Against the oracle at 1e-4
+    and against the one-wave-per-strip form (`softattn_no_pair`) -- the same logits, the log-sum combined in another order."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from oracle import softattn_oracle as S
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 31 + Tx + Ty)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    t_x[0] = Tx
+    pr = torch.rand(B, Tx, Ty, generator=g) if prior else None
+    temp = 0.0005 if sim == "l2" else 0.11
+    want, _ = S.soft_attention(k, q, t_x=t_x, prior=pr, temperature=temp, sim=sim)
+    kw = dict(t_x=t_x.to(dev), prior=None if pr is None else pr.to(dev), temperature=temp, sim=sim)
+    got, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
+    assert lib.aligner_debug_set_option(b"softattn_no_pair", 1) == 0
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"softattn_no_pair", 0))
+    one, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
+    torch.cuda.synchronize()
+    assert _cmp(got, want) < TOL
+    fin = torch.isfinite(one)
+    assert torch.equal(torch.isfinite(got), fin) and (got[fin] - one[fin]).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,C,Tx,Ty", [(8, 80, 200, 1000), (5, 80, 77, 300), (8, 128, 224, 257)])
 def test_logp_only_path(dev, B, C, Tx, Ty):
     """No soft output, no prior: the store path the benchmark and the DP pipeline use."""
