@@ -1207,8 +1207,8 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
 // replay on this stack.)  Zero workgroups never wait, and they come first in dispatch order.
 template <int NW, int DEPTH, bool VEC, int MASKMODE, int VT, bool PAIR = false>
 __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathParams p) {
-    const int Z = PAIR ? 0 : p.zero_blocks;
-    if (!PAIR && (int)blockIdx.x < Z) {
+    const int Z = p.zero_blocks;
+    if ((int)blockIdx.x < Z) {
         // Agent-scope stores (sc1: written through this XCD's L2), then wait for them, then a RELAXED count: no
         // release / acquire anywhere.  A release at agent scope writes the whole L2 back and an acquire invalidates it --
         // per workgroup, under the other workgroups' sweeps: the first version of this, with a fence and a release
@@ -1231,13 +1231,13 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
     } else {
         maxpath_pipelined_body<NW, DEPTH, VEC, MASKMODE, VT, PAIR>(p, (int)blockIdx.x - Z);
     }
-    if (!PAIR && Z > 0) {
+    if (Z > 0) {
         // the last workgroup to finish leaves both counters at 0 for the next launch (launches that share a workspace
         // are ordered on their stream)
         __syncthreads();
         if (threadIdx.x == 0) {
             const int f = __hip_atomic_fetch_add(p.zsync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (f == Z + p.B - 1) {
+            if (f == Z + (PAIR ? 2 : 1) * p.B - 1) {
                 __hip_atomic_store(p.zsync, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p.zsync + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(256) void xring_fill_kernel(uint4 *dst, int n16) {
 
 // two workgroups per utterance (grid 2B), 16-byte loaders only
 static int launch_pair(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
-    dim3 grid(2 * p.B), block(4 * 128);
+    dim3 grid(2 * p.B + p.zero_blocks), block(4 * 128);
     if (vt == VT_BF16) {
         if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_BF16, true>, grid, block, lds, s, p);
         return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_BF16, true>, grid, block, lds, s, p);
@@ -1536,6 +1536,18 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
             hipLaunchKernelGGL(xring_fill_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s,
                                reinterpret_cast<uint4 *>(wsb + L.xring_off), n16);
             ALIGNER_HIP_CHECK(hipGetLastError());
+            {   // the dense path inside this launch (see the kernel): zero workgroups on the CUs the 2B halves leave idle
+                const int cus = device_cu_count();
+                const size_t pbytes = path_out ? (size_t)B * Tx * Ty * dtype_size(path_dtype) : 0;
+                if (path_out && !path_is_zero && !(flags & ALIGNER_F_SEPARATE_EXPAND) && cus - 2 * B >= 32 &&
+                    (reinterpret_cast<uintptr_t>(path_out) & 15) == 0 && pbytes % 16 == 0 && dtype_size(path_dtype) > 0) {
+                    p.zero_blocks = cus - 2 * B;
+                    p.zero_nt = (flags & ALIGNER_F_STREAM_PATH) ? 1 : 0;
+                    p.zero_n16 = pbytes / 16;
+                    set_path_ones(p, path_out, path_dtype);
+                    if (path_done) *path_done = true;
+                }
+            }
             return launch_pair(p, maskmode, vt, lds, s);
         }
     }

@@ -557,7 +557,7 @@ def run_c5(args, world: int):
     cells = Bc * Tx * Ty
     stages = {
         "similarity, bf16 log-probs (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(kk, qq, t_x=tx, logp_dtype=torch.bfloat16), it, dev), 4 * Bc * Ca * (Tx + Ty) + 2 * cells),
-        "alignment search on bf16 + int32 dense path (maxpath_pipelined_kernel x2 CUs + expand)": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, path_dtype=torch.int32), it, dev), 2 * cells + 4 * cells),
+        "alignment search on bf16 + int32 dense path (maxpath_pipelined_kernel, two workgroups per utterance, the path written inside the launch)": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, path_dtype=torch.int32), it, dev), 2 * cells + 4 * cells),
         "alignment search, durations only": (event_time_us(lambda: aligner_amd.align(lp, tx, ty, want_path=False), it, dev), 2 * cells),
         f"boundary search, max duration {D} (norm + max-product chain + backtrack kernels)": (event_time_us(lambda: aligner_amd.boundary_search(lp, tx, ty, D), it, dev), 2 * cells + 4 * cells + 2 * cells + 4 * cells + 2 * cells),
     }
