@@ -55,7 +55,7 @@ struct SoftAttnParams {
     float temperature;
     int sim;
     int out16;              // logp is written as bf16 (round to nearest even)
-    int pair;               // row-group form on a small batch: two waves share a 32-frame strip, each half the row tiles
+    int pair;               // row-group form on a small batch: 2 or 4 waves share a 32-frame strip, each a part of the row tiles (0: one wave)
 };
 
 constexpr int SA_WAVES = 8;                       // waves per workgroup: 8 x 32 = 256 mel frames share one staged text operand
@@ -327,8 +327,9 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
     // (row-group form, p.pair: the workgroup covers 128 frames, waves w and w + 4 share strip w and take the even / odd
     // row tiles of every group -- a strip of long text is a long serial job of ONE wave otherwise, and a small batch
     // leaves the chip's other SIMDs idle meanwhile)
-    const bool pair = MULTI && p.pair;
-    const int swv = pair ? SA_WAVES / 2 : SA_WAVES;               // strips per workgroup
+    const int nsp = (MULTI && p.pair > 1) ? p.pair : 1;            // waves per strip
+    const bool pair = nsp > 1;
+    const int swv = SA_WAVES / nsp;                               // strips per workgroup
     const int NQ = (p.Ty + 32 * swv - 1) / (32 * swv);
     int b, fq;
     if ((p.B & 7) == 0) {
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
         b = blockIdx.x / NQ;
         fq = blockIdx.x % NQ;
     }
-    const int col = fq * (32 * swv) + (pair ? (wave & 3) : wave) * 32 + (lane & 31);
+    const int col = fq * (32 * swv) + (wave % swv) * 32 + (lane & 31);
     const bool col_ok = col < p.Ty;
     int tx = p.Tx;
     if (p.t_xs) {
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             __syncthreads();
             stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
-            for (int r = pair ? (wave >> 2) : 0; r < G; r += pair ? 2 : 1) {
+            for (int r = wave / swv; r < G; r += nsp) {
                 float lg[16];
                 tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
                                 row0 + 32 * r + 4 * half, tx, lane);
@@ -670,10 +671,16 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             float2 *sx = reinterpret_cast<float2 *>(Ahi);
             sx[threadIdx.x] = make_float2(m_run, l_run);
             __syncthreads();
-            const float2 o = sx[threadIdx.x ^ 256];
-            const float m_all = fmaxf(m_run, o.x);
+            // every wave of the strip combines the parts in the same order: they must agree on the normaliser to the bit
+            float m_all = NEG_INF_F;
+            for (int q = 0; q < nsp; ++q) m_all = fmaxf(m_all, sx[(q * swv + wave % swv) * 64 + lane].x);
             const float m_fin = (m_all == NEG_INF_F) ? 0.f : m_all;
-            l_run = (m_run == NEG_INF_F ? 0.f : l_run * __expf(m_run - m_fin)) + (o.x == NEG_INF_F ? 0.f : o.y * __expf(o.x - m_fin));
+            float l_all = 0.f;
+            for (int q = 0; q < nsp; ++q) {
+                const float2 o = sx[(q * swv + wave % swv) * 64 + lane];
+                l_all += (o.x == NEG_INF_F) ? 0.f : o.y * __expf(o.x - m_fin);
+            }
+            l_run = l_all;
             m_run = m_all;
         }
         float lse;
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
             __syncthreads();
             stage_text_group<KS, G>(p, b, g, Ahi, Alo, kn, tx, l2, s2);
             __syncthreads();
-            for (int r = pair ? (wave >> 2) : 0; r < G; r += pair ? 2 : 1) {
+            for (int r = wave / swv; r < G; r += nsp) {
                 float lg[16];
                 const int i_lane = row0 + 32 * r + 4 * half;
                 tile_logits<KS>(lg, Ahi + r * KS * 64, Alo + r * KS * 64, bhi, blo, kn + 32 * r, qn, s2, l2,
@@ -1452,9 +1459,17 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
     auto kern = softattn_kernel<KS, G, MULTI>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     SoftAttnParams q = p;
-    q.pair = (MULTI && !g_opt_softattn_no_pair && (long long)((p.Ty + 32 * SA_WAVES - 1) / (32 * SA_WAVES)) * p.B < device_cu_count() &&
-              p.Ty > 128) ? 1 : 0;
-    const int swv = q.pair ? SA_WAVES / 2 : SA_WAVES;
+    q.pair = 0;
+    if (MULTI && !g_opt_softattn_no_pair) {
+        const long long cus = device_cu_count();
+        auto wgs = [&](int nsp) { return (long long)((p.Ty + 32 * (SA_WAVES / nsp) - 1) / (32 * (SA_WAVES / nsp))) * p.B; };
+        if (g_opt_softattn_split > 1) q.pair = g_opt_softattn_split;
+        // as many waves per strip as still leave every workgroup a CU of its own (measured, one / two / four waves per
+        // strip: [8,500,4000] 81 / 55 / 69 us, [4,500,4000] 78 / 52 / 39, [16,400,2000] 61 / 42 / 54, [2,300,1000] 51 / 35 / 26)
+        else if (wgs(4) <= cus && p.Ty > 64 && g_opt_softattn_split != 1) q.pair = 4;
+        else if (wgs(2) <= cus && p.Ty > 128) q.pair = 2;
+    }
+    const int swv = q.pair > 1 ? SA_WAVES / q.pair : SA_WAVES;
     dim3 grid((unsigned)((p.Ty + 32 * swv - 1) / (32 * swv)) * (unsigned)p.B), block(SA_THREADS);
     hipLaunchKernelGGL(kern, grid, block, lds, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());

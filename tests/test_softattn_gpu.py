@@ -52,9 +52,9 @@ def test_logp_matches_oracle(dev, B, C, Tx, Ty, sim):
 
 @pytest.mark.parametrize("B,C,Tx,Ty,sim,prior", [(2, 80, 300, 700, "l2", False), (1, 80, 500, 1000, "l2", True), (3, 80, 230, 130, "dot", False),
                                                   (2, 128, 260, 257, "l2", False), (1, 256, 150, 400, "l2", True), (8, 80, 500, 1030, "l2", False)])
-def test_row_group_form_with_two_waves_per_strip(dev, request, B, C, Tx, Ty, sim, prior):
-    """Long text on a small batch: the row-group form gives every 32-frame strip to TWO waves (even / odd row tiles, their
-    running maxima and sums met through LDS) while one wave per strip would leave SIMDs idle.  Against the oracle at 1e-4
+def test_row_group_form_with_several_waves_per_strip(dev, request, B, C, Tx, Ty, sim, prior):
+    """Long text on a small batch: the row-group form gives every 32-frame strip to two or four waves (the row tiles dealt
+    round-robin, their running maxima and sums met through LDS) while one wave per strip would leave SIMDs idle.  Against the oracle at 1e-4
     and against the one-wave-per-strip form (`softattn_no_pair`) -- the same logits, the log-sum combined in another order."""
     import aligner_amd
     from aligner_amd import _lib
@@ -70,13 +70,19 @@ def test_row_group_form_with_two_waves_per_strip(dev, request, B, C, Tx, Ty, sim
     want, _ = S.soft_attention(k, q, t_x=t_x, prior=pr, temperature=temp, sim=sim)
     kw = dict(t_x=t_x.to(dev), prior=None if pr is None else pr.to(dev), temperature=temp, sim=sim)
     got, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
+    request.addfinalizer(lambda: (lib.aligner_debug_set_option(b"softattn_no_pair", 0), lib.aligner_debug_set_option(b"softattn_split", 0)))
+    forced = []
+    for sp in (2, 4):                                   # both splits whatever the launch would pick
+        assert lib.aligner_debug_set_option(b"softattn_split", sp) == 0
+        forced.append(aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)[0])
+    lib.aligner_debug_set_option(b"softattn_split", 0)
     assert lib.aligner_debug_set_option(b"softattn_no_pair", 1) == 0
-    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"softattn_no_pair", 0))
     one, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
     torch.cuda.synchronize()
     assert _cmp(got, want) < TOL
     fin = torch.isfinite(one)
-    assert torch.equal(torch.isfinite(got), fin) and (got[fin] - one[fin]).abs().max().item() < 2e-5
+    for t in [got] + forced:
+        assert torch.equal(torch.isfinite(t), fin) and (t[fin] - one[fin]).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("B,C,Tx,Ty", [(8, 80, 200, 1000), (5, 80, 77, 300), (8, 128, 224, 257)])
