@@ -355,6 +355,8 @@ int aligner_regulate_f32(const float *h_dev, const int32_t *durations_dev, float
  *   energies_dev   [B,Tx,Ty] of energy_dtype F32, BF16 or F16 (the alignment layout, mel axis contiguous)
  *   boundaries_out_dev [B,Tx] int32: b_i of the most probable boundary sequence (rows >= t_x: t_y); NULL (with
  *                      durations_out_dev and map_score_out_dev NULL as well) when only log_alpha / gamma are wanted
+ *                      (masked energies that leave no boundary sequence are then not reported: log_alpha of the last
+ *                      token's row is -inf everywhere, gamma 0)
  *   durations_out_dev  optional [B,Tx] int32; map_score_out_dev optional [B] fp32 (its log-probability)
  *   log_alpha_out_dev  optional [B,Tx,Ty] fp32: log P(b_i = j) at [i, j-1], -inf where impossible
  *   gamma_out_dev      optional [B,Tx,Ty] fp32 soft alignment P(b_{i-1} <= y < b_i); needs log_alpha_out_dev
