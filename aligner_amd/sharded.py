@@ -53,6 +53,16 @@ def align_durations(value: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -
     return align(value, t_x, t_y, want_path=False, want_durations=True).durations
 
 
+def boundary_durations(max_duration: int) -> Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor]:
+    """An align_fn for sharded_align(): durations [B,Tx] int32 of the MoBoAligner boundary search (its MAP sequence,
+    window `max_duration`) instead of maximum_path's -- BASELINE config 5's other search shards the same way, utterance
+    by utterance, with the same single gather of int32 durations at the end."""
+    def fn(energies: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor) -> torch.Tensor:
+        from .mobo import boundary_search
+        return boundary_search(energies, t_x, t_y, max_duration).durations
+    return fn
+
+
 def gather_durations(local_dur: torch.Tensor, mine: np.ndarray, n_total: int, Tx: int,
                      group=None) -> torch.Tensor:
     """All-gather the per-rank duration blocks and scatter them back into utterance order.

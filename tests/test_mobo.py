@@ -286,3 +286,30 @@ def test_boundary_search_masked_frames_without_any_segmentation(dev):
         want = M.boundary_search_fast(e[b, :tx[b], :ty[b]].astype(np.float64), D)
         assert np.array_equal(r.boundaries[b].cpu().numpy()[:tx[b]], want["boundaries"])
         assert abs(float(r.map_score[b]) - want["map_score"]) < 1e-3
+
+
+@gpu
+def test_sharded_boundary_search_product_path_single_rank(dev):
+    """The multi-GPU entry point with the boundary search as the per-rank compute (sharded.boundary_durations) on a 1-rank
+    RCCL group: LPT order, the gather and the un-permutation around the HIP kernels; durations equal a direct call."""
+    import os
+    import torch.distributed as dist
+    import aligner_amd
+    from aligner_amd import sharded
+    rng = np.random.default_rng(77)
+    n, Tx, Ty, D = 11, 40, 300, 16
+    e = (rng.standard_normal((n, Tx, Ty)) * 2).astype(np.float32)
+    tx = np.array([Tx] + [int(rng.integers(20, Tx + 1)) for _ in range(n - 1)], np.int32)
+    ty = np.array([Ty] + [int(rng.integers(tx[b], min(Ty, tx[b] * D) + 1)) for b in range(1, n)], np.int32)
+    ed = torch.from_numpy(e).to(dev)
+    want = aligner_amd.boundary_search(ed, torch.from_numpy(tx), torch.from_numpy(ty), D).durations
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        got = sharded.sharded_align(lambda idx: ed[torch.as_tensor(idx, device=dev)], tx, ty, Tx,
+                                    align_fn=sharded.boundary_durations(D), device=dev)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(got, want) and bool((got.sum(1).cpu() == torch.from_numpy(ty)).all())

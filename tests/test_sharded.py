@@ -30,6 +30,45 @@ def _oracle_align(value, tx, ty):
     return torch.from_numpy(p.sum(2).astype(np.int32))
 
 
+def _oracle_boundary_durations(D):
+    def fn(value, tx, ty):
+        from oracle import mobo_oracle as M
+        out = np.zeros((value.shape[0], value.shape[1]), np.int32)
+        for b in range(value.shape[0]):
+            I, J = int(tx[b]), int(ty[b])
+            out[b, :I] = M.boundary_search_fast(value[b, :I, :J].numpy().astype(np.float64), D)["durations"]
+        return torch.from_numpy(out)
+    return fn
+
+
+def _worker_bs(rank, world, port, n, Tx, Ty, D, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tx, ty = synth.synth_lengths(n, Tx, Ty // 2, Ty, 9)
+        full_value = synth.synth_value(n, Tx, Ty, 78)
+        got = sharded.sharded_align(lambda idx: torch.from_numpy(full_value[idx]), tx, ty, Tx,
+                                    align_fn=_oracle_boundary_durations(D))
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), got.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_boundary_search_equals_single_process(tmp_path):
+    """The same host logic with the boundary search as the per-rank compute (the oracle here; the product's
+    sharded.boundary_durations(D) runs the HIP kernels: tests/test_mobo.py)."""
+    world, n, Tx, Ty, D = 2, 7, 12, 60, 16
+    port = _free_port()
+    mp.spawn(_worker_bs, args=(world, port, n, Tx, Ty, D, str(tmp_path)), nprocs=world, join=True)
+    tx, ty = synth.synth_lengths(n, Tx, Ty // 2, Ty, 9)
+    want = _oracle_boundary_durations(D)(torch.from_numpy(synth.synth_value(n, Tx, Ty, 78)), torch.from_numpy(tx),
+                                         torch.from_numpy(ty)).numpy()
+    assert (want.sum(1) == ty).all()
+    for r in range(world):
+        assert np.array_equal(np.load(os.path.join(tmp_path, f"rank{r}.npy")), want), f"rank {r}"
+
+
 def _worker(rank, world, port, n, Tx, Ty, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
