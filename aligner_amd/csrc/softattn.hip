@@ -1303,13 +1303,13 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
             bf16x8 ah[AO], al[AO], bh[AT], bl[AT];
 #pragma unroll
             for (int a = 0; a < AO; ++a) {
-                const int idx = sub * WN1 + (tap * TO + wo + 32 * a + l31) * 2 + half;
+                const int idx = sub * WN1 + half * (K * TO) + tap * TO + wo + 32 * a + l31;       // [sub][channel half][tap][out channel]
                 ah[a] = __builtin_bit_cast(bf16x8, Whi[idx]);
                 al[a] = __builtin_bit_cast(bf16x8, Wlo[idx]);
             }
 #pragma unroll
             for (int c = 0; c < AT; ++c) {
-                const int idx = sub * XN1 + (wt + 32 * c + l31 + tap - HALO + F0) * 2 + half;
+                const int idx = sub * XN1 + half * XF + (wt + 32 * c + l31 + tap - HALO + F0);     // [sub][channel half][frame]
                 bh[c] = __builtin_bit_cast(bf16x8, Xhi[idx]);
                 bl[c] = __builtin_bit_cast(bf16x8, Xlo[idx]);
             }
@@ -1328,8 +1328,13 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
         for (int j = 0; j < WTASK; ++j) {
             const int task = tid + NTHR * j;
             if (task < WN) {
-                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + task) = R.wh[j];
-                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + WN + task) = R.wl[j];
+                // LDS keeps the two channel halves of a fragment row apart ([half][tap][out channel]): the 32 lanes of a
+                // half then read CONSECUTIVE 16-byte slots (interleaved, every ds_read_b128 was a 2-4-way bank conflict:
+                // 45 % of the LDS's busy cycles)
+                const int sub = task / WN1, t1 = task - sub * WN1;
+                const int dsti = sub * WN1 + (t1 & 1) * (K * TO) + (t1 >> 1);
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + dsti) = R.wh[j];
+                *reinterpret_cast<u32x4 *>(bufp + 2 * XN + WN + dsti) = R.wl[j];
             }
         }
         if (XV) {
@@ -1345,7 +1350,7 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
 #pragma unroll
                         for (int jj = 0; jj < 8; ++jj)
                             r[jj] = u == 0 ? R.xq[j][jj].x : u == 1 ? R.xq[j][jj].y : u == 2 ? R.xq[j][jj].z : R.xq[j][jj].w;
-                        const int fi = sub * XN1 + (4 * q + u) * 2 + h;
+                        const int fi = sub * XN1 + h * XF + (4 * q + u);
                         pack_split(r, bufp[fi], bufp[XN + fi]);
                     }
                 }
@@ -1354,7 +1359,11 @@ __global__ __launch_bounds__(WO * WT * 64) void conv1d_prepared_kernel(const flo
 #pragma unroll
             for (int j = 0; j < XTASK; ++j) {
                 const int task = tid + NTHR * j;
-                if (task < XN) pack_split(R.xr[j], bufp[task], bufp[XN + task]);
+                if (task < XN) {
+                    const int sub = task / XN1, t1 = task - sub * XN1;
+                    const int fi = sub * XN1 + (t1 & 1) * XF + (t1 >> 1);
+                    pack_split(R.xr[j], bufp[fi], bufp[XN + fi]);
+                }
             }
         }
     };
