@@ -603,6 +603,33 @@ def run_c5(args, world: int):
     print(json.dumps(line), flush=True)
 
 
+def _self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher around it: run the N ranks as children of this process through
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1), let rank 0's JSON line through on stdout and leave
+    with the children's exit code.  Nothing here touches the GPU -- the parent only counts devices -- so no process that
+    has initialised HIP is ever replaced or forked."""
+    import socket
+    import subprocess
+    if any(a in ("c3", "c5") or a.endswith("=c3") or a.endswith("=c5") for a in sys.argv[1:]):
+        raise SystemExit("--config c3 / c5 are one-GPU lines (BASELINE names them for one MI355X); run them with --gpus 1")
+    rehearse = os.environ.get("ALIGNER_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()                # counts devices without creating a HIP context
+    if have < n and not rehearse:
+        raise SystemExit(f"--gpus {n} but only {have} GPU(s) visible (ALIGNER_BENCH_REHEARSE=1 runs all ranks on GPU 0 "
+                         f"over gloo, for rehearsing the multi-rank path on a one-GPU box)")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.run(cmd, env=env).returncode     # stdout / stderr inherited: rank 0 prints the one JSON line
+    if rc != 0:
+        raise SystemExit(rc if rc > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,6 +661,11 @@ def main():
                          "the 512-utterance ragged job; c5: configs[4], long-form bf16 similarity + alignment + boundary search")
     ap.add_argument("--max-duration", type=int, default=32, help="c5: the boundary search's maximum-duration window")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started by hand (or by a driver that does not wrap it in torch.distributed.run): start
+        # the N ranks ourselves, as fresh child processes, BEFORE anything in this process touches the GPU
+        return _self_launch(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -782,17 +814,56 @@ def main():
         steps[0].path_mode = args.path_mode
         steps[0].capture()
 
-    # correctness guard on the timed outputs: every frame has exactly one token, durations sum to T_mel
-    for st in steps:
-        assert bool((st.tok[:, -1] == TX - 1).all())
-        if dist is None:
-            assert int(st.dur.sum().item()) == B * TY
-            assert bool((st.path.sum(2).to(torch.int32) == st.dur).all())       # the dense path IS those durations
-    if dist is not None:
+    # correctness guards on the timed outputs: every frame has exactly one token, durations sum to T_mel, the dense path
+    # IS those durations; N>1: every bucket a gather has read holds complete steps, and what the gather delivered for
+    # this rank is what this rank's kernels wrote
+    guards = {"last_frame_on_last_token": all(bool((st.tok[:, -1] == TX - 1).all()) for st in steps)}
+    if dist is None:
+        guards["durations_sum_to_t_mel"] = all(int(st.dur.sum().item()) == B * TY for st in steps)
+        guards["dense_path_is_the_durations"] = all(bool((st.path.sum(2).to(torch.int32) == st.dur).all()) for st in steps)
+    else:
         filled = min(args.steps + args.warmup, ge)
+        ok_sums, ok_gather = True, True
         for bi in range(2):
             sums = buckets[bi].sum(dim=(1, 2))
-            assert bool(((sums == B * TY) | (sums == 0)).all()) and (bi == 1 or int((sums == B * TY).sum()) >= min(filled, ge))
+            ok_sums &= bool(((sums == B * TY) | (sums == 0)).all()) and (bi == 1 or int((sums == B * TY).sum()) >= min(filled, ge))
+            if done[bi] is not None:
+                ok_gather &= bool((gathered[bi][rank * ge:(rank + 1) * ge] == buckets[bi]).all())
+                gs = gathered[bi].sum(dim=(1, 2))
+                ok_gather &= bool(((gs == B * TY) | (gs == 0)).all())
+        flags = torch.tensor([int(ok_sums), int(ok_gather)], dtype=torch.int32, device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)               # every rank's view
+        guards["durations_sum_to_t_mel"] = bool(flags[0].item())
+        guards["durations_match_gathered"] = bool(flags[1].item())
+    # parity of the timed code path against the reference: one extra UNTIMED pass of the step's own search + dense-path
+    # launches on the scores of SURVEY Appendix A's C2 case, whose path / duration hashes the reference produced
+    # (tests/golden/appendix_a.json, made by tests/golden/make_golden.py from the real Cython core)
+    ref_path = ref_dur = None
+    if rank == 0:
+        try:
+            import hashlib
+            with open(os.path.join(ROOT, "tests", "golden", "appendix_a.json")) as f:
+                rec = json.load(f)["C2-fixed"]
+            st = steps[0]
+            torch.cuda.synchronize(dev)
+            keep = st.logp.clone()
+            st.logp.copy_(torch.from_numpy(synth.synth_value(*synth.CONFIGS["C2"])))
+            st.forward()
+            st.expand()
+            torch.cuda.synchronize(dev)
+            ref_path = hashlib.sha256(st.path.to(torch.int32).cpu().numpy().tobytes()).hexdigest() == rec["path_sha256"]
+            ref_dur = hashlib.sha256(st.dur_out.cpu().numpy().astype(np.int32).tobytes()).hexdigest() == rec["dur_sha256"]
+            st.search_with_path()                                   # the one-launch form of the serial figure, too
+            torch.cuda.synchronize(dev)
+            ref_path = ref_path and hashlib.sha256(st.path.to(torch.int32).cpu().numpy().tobytes()).hexdigest() == rec["path_sha256"]
+            st.logp.copy_(keep)
+            del keep
+        except (OSError, KeyError, ValueError) as e:
+            print(f"[bench] reference-hash pass skipped ({type(e).__name__}: {e})", file=sys.stderr)
+    guards["path_matches_reference_hash"] = ref_path
+    guards["durations_match_reference_hash"] = ref_dur
+    bad = [k for k, v in guards.items() if v is False]
+    assert not bad, f"guards failed on the timed outputs: {bad}"
 
     if rank == 0:
         n = max(world, 1)
@@ -815,29 +886,52 @@ def main():
         side = {"maxpath_pipelined_kernel (search + dense path in one launch)": {"us": t_full, "bytes": 8 * cells + 4 * B * (TX + TY)},
                 "zero_path_kernel": {"us": t_zero, "bytes": 4 * cells},
                 "scatter_path_kernel": {"us": t_scat, "bytes": 4 * B * TY + 4 * B * (TX + 1)}}
-        dom = max(kernels, key=lambda k: kernels[k]["us"])
+        # The roofline object is the similarity kernel's: north_star names THAT kernel for the HBM figure (it is
+        # the HBM-bound one).  The kernel with the longest duration is the alignment search, which SURVEY 8d prices as bound
+        # by neither HBM nor MFMA (a dependent chain of T_mel steps on B of the 256 CUs): it is reported beside it as
+        # `dominant_by_time` with "bound": "latency", its bytes-per-second for information only.
+        dom = "softattn_kernel"
+        longest = max(kernels, key=lambda k: kernels[k]["us"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/pmc_traffic.py; gfx950 FETCH_SIZE correction applied) and committed under profiles/ --
         # not measured by this run, so the line names the file (and with it the build) the figure comes from
-        traffic, traffic_src = None, None
-        for name in ("r03_pmc_hbm_traffic.json", "r02h_pmc_hbm_traffic.json", "r02f_pmc_hbm_traffic.json", "r02d_pmc_hbm_traffic.json", "r02c_pmc_hbm_traffic.json", "r02b_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        traffic, traffic_src, traffic_all = None, None, {}
+        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02h_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic = json.load(f)["kernels"].get(dom, {}).get("hbm_bytes")
+                    traffic_all = json.load(f)["kernels"]
+                traffic = traffic_all.get(dom, {}).get("hbm_bytes")
                 traffic_src = "profiles/" + name
                 break
             except (OSError, ValueError, KeyError):
                 continue
+        # wave occupancy of the search kernel from the SQ counters (rocprofv3 --pmc pass of this command,
+        # tools/pmc_issue.py -> profiles/r04_pmc_issue_counters.json): resident waves over the chip's wave slots while
+        # the kernel runs; falls back to the launch geometry (B workgroups x 8 waves / 8192 slots) when the file is absent
+        occ, occ_src = round(B * 8 / (256 * 32), 4), "launch geometry (B workgroups x 8 waves / 8192 wave slots)"
+        try:
+            with open(os.path.join(ROOT, "profiles", "r04_pmc_issue_counters.json")) as f:
+                pmc = json.load(f)["kernels"]["maxpath_pipelined_kernel"]
+            occ, occ_src = pmc["wave_occupancy"], "profiles/r04_pmc_issue_counters.json (4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8) / 8192 wave slots)"
+        except (OSError, ValueError, KeyError):
+            pass
+        dp_bytes, dp_us = kernels[longest]["bytes"], kernels[longest]["us"]
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel_us": round(kernels[dom]["us"], 2), "algorithmic_bytes": kernels[dom]["bytes"],
-                    # the DP launches one 8-wave workgroup per utterance: waves resident / wave slots of the chip
-                    "dp_wave_occupancy": round(B * 8 / (256 * 32), 4),
-                    # informational: this launch runs on B of the 256 CUs, and one CU takes in at most
-                    # ~64 GB/s (measured: the kernel's loader waves running free; the guide's 66-73 GB/s for L2-
-                    # resident rows) -- the memory bound of THIS launch is B x 64 GB/s, not the chip's peak
-                    "launch_fetch_bound_GBps": round(min(B, 256) * 64.0, 1),
+                    "dominant_by_time": {
+                        "kernel": longest, "bound": "latency", "kernel_us": round(dp_us, 2),
+                        "algorithmic_bytes": dp_bytes, "achieved": round(dp_bytes / (dp_us * 1e-6) / 1e9, 1), "unit": "GB/s",
+                        "frac_of_hbm_peak": round(dp_bytes / (dp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": traffic_all.get(longest, {}).get("hbm_bytes"),
+                        "wave_occupancy": occ, "wave_occupancy_source": occ_src,
+                        # informational: this launch runs on B of the 256 CUs, and one CU takes in at most
+                        # ~64 GB/s (the guide's 66-73 GB/s for L2-resident rows): its memory bound is B x 64 GB/s
+                        "launch_fetch_bound_GBps": round(min(B, 256) * 64.0, 1),
+                        "note": "SURVEY 8d: bound by neither HBM nor MFMA -- a dependent chain of T_mel frames on B of the "
+                                "256 CUs; bytes per second are for information"},
+                    "dp_wave_occupancy": occ,
                     "all_kernels": {k: {"us": round(v["us"], 2),
                                         "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                                         "frac_of_8000": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
@@ -871,6 +965,7 @@ def main():
                        "parallelism": f"batch-sharded x{n}" + (f", RCCL all_gather of durations every "
                                                                f"{ge} steps" if n > 1 else "")},
             "roofline": roofline,
+            "guards": guards,
         }
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev)

@@ -294,6 +294,8 @@ int aligner_conv1d_prepared_f32(const float *x_dev, const void *prepared_dev, co
  * prior) + the lengths; outputs as aligner_maxpath_forward (token starts in the workspace: aligner_maxpath_expand
  * gives the dense path).  The path is bit-identical to aligner_maxpath on the logp this call writes.
  * Limits: C <= 80, Tx <= 252, Ty <= 2048, finite encodings; ALIGNER_EDOM otherwise.  Workspace as aligner_maxpath.
+ * EXPERIMENT, closed as "measured, loses": 126 us against 53 us for aligner_softattn_f32 + aligner_maxpath_forward_f32 at
+ * [64,80,200,1000] (all of logp leaves through the B CUs the search runs on); kept for the measurement record only.
  */
 int aligner_fused_align_f32(const float *keys_dev, const float *queries_dev,
                             const int32_t *t_xs_dev, const int32_t *t_ys_dev,

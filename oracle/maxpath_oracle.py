@@ -2,7 +2,7 @@
 
 CPU oracle for the monotonic-alignment hot path.  Only tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
-aligner_amd/ never does (tests/test_no_oracle_in_product.py enforces it).
+aligner_amd/ never does (tests/test_abi.py::test_product_never_imports_the_oracle enforces it).
 
 What is here (reference paths relative to /root/reference):
 

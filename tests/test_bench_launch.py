@@ -1,0 +1,50 @@
+"""`python bench.py --gpus N` starts its own ranks (no torch.distributed.run around it) -- CPU-side checks.
+
+The N-rank path itself needs GPUs; here: the parent never touches the GPU, spawns the ranks through
+torch.distributed.run on 127.0.0.1, and propagates a failing child (on this GPU-less container every rank fails loudly in
+`_lib.require_gpu()`, which is exactly the exit the parent must hand on)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra, timeout=300):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def _no_gpu():
+    import torch
+    return torch.cuda.device_count() == 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the GPU-less behaviour")
+def test_self_launch_refuses_more_ranks_than_gpus():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {})
+    assert r.returncode != 0
+    assert "only 0 GPU(s) visible" in r.stderr
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="checks the GPU-less behaviour")
+def test_self_launch_starts_ranks_and_propagates_their_failure():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {"ALIGNER_BENCH_REHEARSE": "1"})
+    assert r.returncode != 0                                    # the ranks' failure is the parent's
+    # the children were really started by torch.distributed.run (its failure report names both ranks) ...
+    assert "bench.py FAILED" in r.stderr or "ChildFailedError" in r.stderr
+    # ... and died where the product refuses to run without a GPU (no fallback of any kind)
+    assert "GPU" in r.stderr
+    assert r.stdout.strip() == ""                              # no JSON line from a failed job
+
+
+def test_one_gpu_configs_refuse_n_ranks():
+    r = _run(["--gpus", "2", "--config", "c3"], {"ALIGNER_BENCH_REHEARSE": "1"})
+    assert r.returncode != 0 and "one-GPU" in r.stderr

@@ -1,9 +1,12 @@
-"""Fused similarity -> log-softmax -> alignment search (no reference counterpart).
+"""Fused similarity -> log-softmax -> alignment search (no reference counterpart) -- closed as
+"measured, loses" and kept in aligner_amd.experimental for the record; this keeps its parity green.
 Log-probabilities against the fp32 oracle at 1e-4 (parity UNPINNED, as for the unfused front end); the path
 against the pinned maximum_path oracle run on the log-probabilities the fused kernel itself wrote (bit-exact)."""
 import numpy as np
 import pytest
 import torch
+
+from aligner_amd.experimental import fused_align
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +36,7 @@ def test_fused_matches_unfused_semantics(dev, B, C, Tx, Ty, sim):
     t_x = torch.minimum(torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32), t_y)
     t_x[0], t_y[0] = Tx, Ty
     temp = 0.0005 if sim == "l2" else 0.11
-    logp, res = aligner_amd.fused_align(k.to(dev), q.to(dev), t_x.to(dev), t_y.to(dev), temperature=temp, sim=sim,
+    logp, res = fused_align(k.to(dev), q.to(dev), t_x.to(dev), t_y.to(dev), temperature=temp, sim=sim,
                                         path_dtype=torch.int32, want_tok=True)
     torch.cuda.synchronize()
     want = _oracle_logp(k, q, t_x, temperature=temp, sim=sim)
@@ -58,7 +61,7 @@ def test_fused_without_logp_output(dev):
     k, q = torch.randn(4, 80, 200, generator=g).to(dev), torch.randn(4, 80, 1000, generator=g).to(dev)
     t_x = torch.tensor([200, 150, 99, 30], dtype=torch.int32, device=dev)
     t_y = torch.tensor([1000, 800, 640, 333], dtype=torch.int32, device=dev)
-    _, a = aligner_amd.fused_align(k, q, t_x, t_y, path_dtype=torch.int32)
-    none, bres = aligner_amd.fused_align(k, q, t_x, t_y, want_logp=False, path_dtype=torch.int32)
+    _, a = fused_align(k, q, t_x, t_y, path_dtype=torch.int32)
+    none, bres = fused_align(k, q, t_x, t_y, want_logp=False, path_dtype=torch.int32)
     torch.cuda.synchronize()
     assert none is None and torch.equal(a.path, bres.path) and torch.equal(a.durations, bres.durations)
