@@ -28,6 +28,7 @@ F_TWO_CUS = 512
 F_TEST_DROP_FIRST_HALF = 1024
 F_PATH_PREZEROED = 2048
 F_SEPARATE_EXPAND = 4096
+F_TEST_DROP_ZERO_REPORTS = 8192
 
 ST_BAD_LENGTHS = 1
 ST_CLAMPED = 2

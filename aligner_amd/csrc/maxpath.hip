@@ -187,6 +187,28 @@ __device__ __forceinline__ int starts_words_of(int Tx) { return ((Tx + 1 + 63) /
 __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, int *startsL,
                                               bool distinct_starts = true) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
+    if (p.path1 && p.zero_blocks > 0) {
+        // The zeros of the dense path come from the launch's zero workgroups: all of them must have reported before a 1 is
+        // written (a 1 written earlier could be wiped by a zero store still on its way).  The wait is bounded; a
+        // workgroup that gives up leaves a DEFINED result -- no 1 anywhere in its block (which the zero workgroups, who
+        // never wait for anybody, turn into all zeros whenever they do run), zero durations, no token on any frame,
+        // ALIGNER_ST_INTERNAL in the status word -- never ones that a late zero workgroup may or may not erase.
+        int gave_up = 0;
+        if (tid == 0) {
+            const int limit = (p.flags & ALIGNER_F_TEST_DROP_ZERO_REPORTS) ? (1 << 10) : ZERO_SPIN_LIMIT;
+            int spins = 0;
+            while (__hip_atomic_load(p.zsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.zero_blocks) {   // (relaxed: see the kernel)
+                if (++spins > limit) { atomicOr(p.status, ALIGNER_ST_INTERNAL); gave_up = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (__syncthreads_or(gave_up)) {
+            for (int x = tid; x <= p.Tx; x += nthreads) startsL[x] = 0;
+            __syncthreads();
+            tx = 0;
+            ty = 0;
+        }
+    }
     for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
         for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
@@ -201,17 +223,6 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
             default: static_cast<unsigned long long *>(p.path1)[idx] = p.path1_one; break;
         }
     };
-    if (p.path1 && p.zero_blocks > 0) {
-        // the zeros come from the launch's zero workgroups: all of them must have reported before a 1 is written
-        if (tid == 0) {
-            int spins = 0;
-            while (__hip_atomic_load(p.zsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.zero_blocks) {   // (relaxed: see the kernel)
-                if (++spins > ZERO_SPIN_LIMIT) { atomicOr(p.status, ALIGNER_ST_INTERNAL); break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        __syncthreads();
-    }
     const int nmw = (ty + 31) >> 5;                        // words of the bit string
     unsigned *mark = reinterpret_cast<unsigned *>(startsL + starts_words_of(p.Tx));
     int *before = reinterpret_cast<int *>(mark + nmw);    // set bits in the words before word j
@@ -1227,7 +1238,8 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's zeros have left for memory ...
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(p.zsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the workgroup says so
+        if (threadIdx.x == 0 && !(p.flags & ALIGNER_F_TEST_DROP_ZERO_REPORTS))                  // (testing: the zeros are written, never reported)
+            __hip_atomic_fetch_add(p.zsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the workgroup says so
     } else {
         maxpath_pipelined_body<NW, DEPTH, VEC, MASKMODE, VT, PAIR>(p, (int)blockIdx.x - Z);
     }

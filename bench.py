@@ -625,7 +625,15 @@ def _self_launch(n: int) -> None:
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    rc = subprocess.run(cmd, env=env).returncode     # stdout / stderr inherited: rank 0 prints the one JSON line
+    # stderr inherited; of the ranks' stdout only rank 0's JSON line goes to ours (libraries chat on stdout: gloo does)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:
+        if ln.startswith("{"):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
     if rc != 0:
         raise SystemExit(rc if rc > 0 else 1)
 

@@ -98,6 +98,10 @@ extern "C" {
 #define ALIGNER_F_TEST_DROP_FIRST_HALF 1024 /* testing: in the two-workgroup form the first half of every utterance leaves
                                       without delivering, so the second gives up after its bounded wait: all-zero
                                       path, zero durations, ALIGNER_ST_INTERNAL -- the defined failure of that form */
+#define ALIGNER_F_TEST_DROP_ZERO_REPORTS 8192 /* testing: the zero workgroups of the one-launch dense path (above) write their
+                                      zeros but never report, so every utterance's workgroup gives up after a (here
+                                      shortened) bounded wait -- the defined failure of that form: no 1 in the path
+                                      (all zeros), zero durations, no token on any frame, ALIGNER_ST_INTERNAL */
 #define ALIGNER_F_WRITE_Q       64 /* also overwrite the fp32 score block with the running scores Q inside
                                       the band, in place, exactly as the reference does (core.pyx:18,30:
                                       `value[x, y] = max(v_cur, v_prev) + value[x, y]`).  Takes the

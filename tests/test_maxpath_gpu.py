@@ -670,6 +670,50 @@ def test_two_workgroups_first_half_never_delivers(dev):
     assert np.array_equal(p, want) and aligner_amd.read_status(dev) == 0
 
 
+def test_zero_workgroups_never_report_is_a_defined_failure(dev):
+    """The defined failure of the one-launch dense path (zero workgroups beside the search): if the zero
+    workgroups do not report (here: the test flag -- they write their zeros and keep quiet), every utterance's workgroup
+    gives up after its bounded wait and writes NO one at all: the path comes back all zeros (never ones that a late zero
+    workgroup might erase), durations zero, no token on any frame, ALIGNER_ST_INTERNAL raised; check=True raises, the
+    blocking host form returns an error, and the next call is fine (the last workgroup resets both counters)."""
+    import aligner_amd
+    from aligner_amd import _lib
+    rng = np.random.default_rng(11)
+    B, Tx, Ty = 5, 70, 336                                   # B*Tx*Ty % 16 == 0: the zero workgroups store 16 bytes at a time
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([70, 33, 1, 64, 70], np.int32); ty = np.array([336, 200, 9, 336, 70], np.int32)
+    want = _oracle_path(v, tx, ty)
+    assert aligner_amd.read_status(dev) == 0
+    for dt in (torch.float32, torch.int32, torch.bfloat16, torch.uint8):
+        vt, txt, tyt = torch.from_numpy(v).to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+        r = aligner_amd.align(vt, txt, tyt, path_dtype=dt, want_tok=True, _test_flags=_lib.F_TEST_DROP_ZERO_REPORTS)
+        torch.cuda.synchronize()
+        assert aligner_amd.read_status(dev) & _lib.ST_INTERNAL, "the zero workgroups were not part of this launch?"
+        assert not r.path.to(torch.float32).any() and not r.durations.any() and bool((r.tok == -1).all())
+        r = aligner_amd.align(vt, txt, tyt, path_dtype=dt, want_tok=True)                # the same call without the fault
+        assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), want) and aligner_amd.read_status(dev) == 0
+        assert np.array_equal(r.durations.cpu().numpy(), want.sum(2))
+    with pytest.raises(RuntimeError, match="internal consistency"):
+        aligner_amd.align(vt, txt, tyt, _test_flags=_lib.F_TEST_DROP_ZERO_REPORTS, check=True)
+    assert aligner_amd.read_status(dev) & _lib.ST_INTERNAL
+    lib = _lib.load()
+    paths = np.zeros((B, Tx, Ty), np.int32)
+    vals = v.copy()
+    rc = lib.aligner_maxpath_host_f32(paths.ctypes.data, vals.ctypes.data, tx.ctypes.data, ty.ctypes.data, B, Tx, Ty, -1e9,
+                                      _lib.F_TEST_DROP_ZERO_REPORTS)
+    assert rc == -5 and b"internal consistency" in lib.aligner_last_error() and not paths.any()
+    # the two-workgroup form carries zero workgroups too
+    B2, Tx2, Ty2 = 2, 300, 1900
+    v2 = rng.standard_normal((B2, Tx2, Ty2)).astype(np.float32)
+    tx2 = np.array([300, 290], np.int32); ty2 = np.array([1900, 1800], np.int32)
+    want2 = _oracle_path(v2, tx2, ty2)
+    p, tok, dur = _hip(v2, tx2, ty2, dev, cus_per_utterance=2, _test_flags=_lib.F_TEST_DROP_ZERO_REPORTS)
+    assert aligner_amd.read_status(dev) & _lib.ST_INTERNAL
+    assert not p.any() and not dur.any() and np.all(tok == -1)
+    p, tok, dur = _hip(v2, tx2, ty2, dev, cus_per_utterance=2)
+    assert np.array_equal(p, want2) and aligner_amd.read_status(dev) == 0
+
+
 def test_workspace_regrowth_keeps_the_status_word(dev):
     """A workspace that has to grow is replaced; the sticky status bits raised through the old one must survive
     until read_status() (StreamWorkspaces.get carries the word over on the stream)."""
