@@ -71,6 +71,8 @@ SIGNATURES = {
     "aligner_conv1d_prepared_bytes": (_sz, [_i, _i, _i]),
     "aligner_conv1d_prepare_f32": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_conv1d_prepared_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "aligner_conv1d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "aligner_conv1d_prepared_ws_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
     "aligner_forward_sum_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_forward_sum_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_forward_sum_ctc_workspace_bytes": (_sz, [_i, _i, _i]),

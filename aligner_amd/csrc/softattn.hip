@@ -36,6 +36,14 @@
 
 namespace aligner {
 
+// convgemm.hip: the wide layers' GEMM-structured convolution (operands pre-split, LDS-DMA staging)
+bool conv_gemm_applies(int Cin, int Cout, int K);
+size_t conv_gemm_prepared_bytes(int Cout, int Cin, int K);
+size_t conv_gemm_workspace_bytes(int B, int Cin, int Cout, int T, int K);
+int conv_gemm_prepare(const float *w, void *prepared, int Cout, int Cin, int K, hipStream_t s);
+int conv_gemm_run(const float *x, const void *prepared, const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                  int B, int Cin, int Cout, int T, int K, int relu, hipStream_t s);
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -1556,9 +1564,17 @@ int aligner_softattn(const float *keys, const float *queries, const int32_t *t_x
     return multi ? launch_softattn<16, 4, true>(p, ws, L, s) : launch_softattn<16, 4, false>(p, ws, L, s);
 }
 
+// prepared weights = [conv1d_prepared_kernel's image][for wide layers (conv_gemm_applies): conv_gemm_kernel's image]
+static size_t conv_prep_first_bytes(int Cout, int Cin, int K) { return align_up(conv_prep_layout(Cout, Cin, K).total, 256); }
+
 size_t aligner_conv1d_prepared_bytes(int Cout, int Cin, int K) {
     if (Cout < 1 || Cin < 1 || (K != 1 && K != 3 && K != 5)) return 0;
-    return conv_prep_layout(Cout, Cin, K).total;
+    return conv_prep_first_bytes(Cout, Cin, K) + (conv_gemm_applies(Cin, Cout, K) ? conv_gemm_prepared_bytes(Cout, Cin, K) : 0);
+}
+
+size_t aligner_conv1d_workspace_bytes(int B, int Cin, int Cout, int T, int K) {
+    if (B < 1 || Cout < 1 || Cin < 1 || T < 1 || !conv_gemm_applies(Cin, Cout, K)) return 0;
+    return conv_gemm_workspace_bytes(B, Cin, Cout, T, K);
 }
 
 int aligner_conv1d_prepare_f32(const float *w, void *prepared, size_t prepared_bytes, int Cout, int Cin, int K,
@@ -1567,13 +1583,31 @@ int aligner_conv1d_prepare_f32(const float *w, void *prepared, size_t prepared_b
     if (Cout < 1 || Cin < 1) return fail(ALIGNER_EINVAL, "bad shape");
     if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
     const ConvPrep L = conv_prep_layout(Cout, Cin, K);
-    if (prepared_bytes < L.total) return fail(ALIGNER_ENOSPC, "prepared buffer %zu < %zu bytes", prepared_bytes, L.total);
+    const size_t need = aligner_conv1d_prepared_bytes(Cout, Cin, K);
+    if (prepared_bytes < need) return fail(ALIGNER_ENOSPC, "prepared buffer %zu < %zu bytes", prepared_bytes, need);
     unsigned char *pp = static_cast<unsigned char *>(prepared);
     const int nfrag = L.nch * K * L.cpad * 2;
     hipLaunchKernelGGL(conv_prep_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        reinterpret_cast<uint4 *>(pp), reinterpret_cast<uint4 *>(pp + L.lo_off), Cout, Cin, K, L.cpad, nfrag);
     ALIGNER_HIP_CHECK(hipGetLastError());
+    if (conv_gemm_applies(Cin, Cout, K))
+        return conv_gemm_prepare(w, pp + conv_prep_first_bytes(Cout, Cin, K), Cout, Cin, K, static_cast<hipStream_t>(stream));
     return ALIGNER_OK;
+}
+
+int aligner_conv1d_prepared_ws_f32(const float *x, const void *prepared, const float *bias, float *y, void *workspace,
+                                   size_t workspace_bytes, int B, int Cin, int Cout, int T, int K, int relu, void *stream) {
+    if (!x || !prepared || !y) return fail(ALIGNER_EINVAL, "null pointer");
+    if (B < 0 || Cin < 1 || Cout < 1 || T < 1) return fail(ALIGNER_EINVAL, "bad shape");
+    if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
+    if (B == 0) return ALIGNER_OK;
+    static const bool no_gemm = [] { const char *e = getenv("ALIGNER_CONV_NO_GEMM"); return e && e[0] == '1'; }();
+    if (!conv_gemm_applies(Cin, Cout, K) || no_gemm)      // narrow layers: conv1d_prepared_kernel, no workspace needed
+        return aligner_conv1d_prepared_f32(x, prepared, bias, y, B, Cin, Cout, T, K, relu, stream);
+    if (!workspace) return fail(ALIGNER_EINVAL, "this layer needs aligner_conv1d_workspace_bytes() of workspace");
+    const unsigned char *pp = static_cast<const unsigned char *>(prepared);
+    return conv_gemm_run(x, pp + conv_prep_first_bytes(Cout, Cin, K), bias, y, workspace, workspace_bytes, B, Cin, Cout, T, K,
+                         relu, static_cast<hipStream_t>(stream));
 }
 
 int aligner_conv1d_prepared_f32(const float *x, const void *prepared, const float *bias, float *y, int B, int Cin,

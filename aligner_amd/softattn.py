@@ -32,6 +32,7 @@ def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 _workspaces = _lib.StreamWorkspaces(zero=False)
+_conv_workspaces = _lib.StreamWorkspaces(zero=False)      # split activations of the wide conv layers
 _prepared: dict = {}          # (weight ptr, shape, device, stream) -> (version, prepared weights, weight)
 
 
@@ -76,9 +77,13 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
             _prepared[key] = (weight._version, prep, weight)   # holding `weight` keeps its address from being reused
         else:
             prep = ent[1]
-        _lib.check(lib.aligner_conv1d_prepared_f32(x.data_ptr(), prep.data_ptr(),
-                                                   None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                                   B, Cin, Cout, T, K, int(relu), _stream(x.device)))
+        # wide layers split their activations into a workspace first (csrc/convgemm.hip); narrow ones need none
+        nws = lib.aligner_conv1d_workspace_bytes(B, Cin, Cout, T, K)
+        ws = _conv_workspaces.get(x.device, nws) if nws else None
+        _lib.check(lib.aligner_conv1d_prepared_ws_f32(x.data_ptr(), prep.data_ptr(),
+                                                      None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                                      None if ws is None else ws.data_ptr(), nws,
+                                                      B, Cin, Cout, T, K, int(relu), _stream(x.device)))
     return y
 
 

@@ -290,6 +290,18 @@ int aligner_conv1d_prepare_f32(const float *w_dev, void *prepared_dev, size_t pr
 int aligner_conv1d_prepared_f32(const float *x_dev, const void *prepared_dev, const float *bias_dev,
                                 float *y_dev, int B, int Cin, int Cout, int T, int K,
                                 int relu, void *stream);
+/*
+ * ... and with a workspace, which the WIDE layers (Cout >= 128, Cin >= 64: the text encoder's 512 -> 1024 k=3) need for
+ * their fast form: the activations are split into bf16 halves and transposed to channels-last fragments by a streaming
+ * pass into the workspace (aligner_conv1d_workspace_bytes(B,Cin,Cout,T,K) bytes, 16-byte aligned; 0 = this layer needs
+ * none), then a GEMM-structured kernel multiplies them with the prepared weights -- activations global -> LDS by
+ * LDS-DMA, the weights' fragments straight into registers, nothing waited for inside the loop (csrc/convgemm.hip).
+ * Narrow layers take the kernel of aligner_conv1d_prepared_f32 and ignore the workspace.  Same numerics as above.
+ */
+size_t aligner_conv1d_workspace_bytes(int B, int Cin, int Cout, int T, int K);
+int aligner_conv1d_prepared_ws_f32(const float *x_dev, const void *prepared_dev, const float *bias_dev,
+                                   float *y_dev, void *workspace_dev, size_t workspace_bytes,
+                                   int B, int Cin, int Cout, int T, int K, int relu, void *stream);
 
 /*
  * Similarity -> log-softmax -> alignment search in ONE kernel (no reference

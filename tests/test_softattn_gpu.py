@@ -197,6 +197,46 @@ def test_conv1d_and_full_encoder(dev):
     assert _cmp(got, want) < TOL
 
 
+@pytest.mark.parametrize("B,Ci,Co,T,K,relu", [
+    (3, 512, 1024, 200, 3, True),      # the C3 text encoder's wide layer: one 13-tile workgroup per utterance
+    (2, 64, 128, 16, 1, False),        # the smallest shape the GEMM form takes
+    (2, 100, 130, 201, 3, True),       # channels not a multiple of 32 / 128, T % 4 != 0 (scalar stores)
+    (2, 96, 256, 900, 5, False),       # several frame tiles per utterance, k = 5 (two halo frames)
+    (1, 256, 384, 129, 1, True),       # T just over 128: the 13-tile form with most of it empty
+    (2, 70, 200, 1000, 3, True),       # 8-tile workgroups (1000 frames: 1024 vs 1040)
+])
+def test_wide_conv_gemm_form(dev, B, Ci, Co, T, K, relu):
+    """csrc/convgemm.hip (activations split + LDS-DMA staging + weight fragments in registers) against the fp32 oracle at
+    1e-4, and against the round-3 kernel it replaces on these layers (same bf16x3 products: agreement far inside that)."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from oracle import softattn_oracle as S
+    lib = _lib.load()
+    assert lib.aligner_conv1d_workspace_bytes(B, Ci, Co, T, K) > 0, "this shape is meant to take the GEMM form"
+    g = torch.Generator().manual_seed(B * 1000 + Ci + T)
+    x = torch.randn(B, Ci, T, generator=g)
+    w = torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5
+    b = torch.randn(Co, generator=g)
+    want = S.conv1d(x, w, b, relu)
+    got = aligner_amd.conv1d(x.to(dev), w.to(dev), b.to(dev), relu)
+    torch.cuda.synchronize()
+    assert (got.cpu() - want).abs().max().item() < 1e-4
+    # the round-3 kernel through the workspace-free entry point, on the same prepared buffer
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    n = lib.aligner_conv1d_prepared_bytes(Co, Ci, K)
+    prep = torch.empty(n, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.aligner_conv1d_prepare_f32(wd.data_ptr(), prep.data_ptr(), n, Co, Ci, K, st))
+    y_old = torch.empty(B, Co, T, device=dev)
+    _lib.check(lib.aligner_conv1d_prepared_f32(xd.data_ptr(), prep.data_ptr(), bd.data_ptr(), y_old.data_ptr(), B, Ci, Co, T, K,
+                                               int(relu), st))
+    torch.cuda.synchronize()
+    assert (got - y_old).abs().max().item() < 2e-5
+    # no bias
+    got = aligner_amd.conv1d(xd, wd, None, relu)
+    assert (got.cpu() - S.conv1d(x, w, None, relu)).abs().max().item() < 1e-4
+
+
 def test_pipeline_similarity_then_dp(dev):
     """configs[1]: similarity + DP.  The hard path from the HIP log-probs equals the
     oracle DP run on the same log-probs (bit-exact integer path)."""
