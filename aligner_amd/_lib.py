@@ -40,6 +40,13 @@ SIM_DOT = 1
 _c = ctypes
 _vp, _i, _f, _sz = _c.c_void_p, _c.c_int, _c.c_float, _c.c_size_t
 
+
+class ConvLayer(ctypes.Structure):
+    """struct aligner_conv_layer (include/aligner_amd.h): one layer of an encoder stack."""
+    _fields_ = [("prepared", _c.c_void_p), ("bias", _c.c_void_p),
+                ("Cin", _c.c_int), ("Cout", _c.c_int), ("K", _c.c_int), ("relu", _c.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/aligner_amd.h declares
 SIGNATURES = {
     "aligner_abi_version": (_i, []),
@@ -73,6 +80,8 @@ SIGNATURES = {
     "aligner_conv1d_prepared_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aligner_conv1d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "aligner_conv1d_prepared_ws_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp]),
+    "aligner_conv_stack_workspace_bytes": (_sz, [_c.POINTER(ConvLayer), _i, _i, _i]),
+    "aligner_conv_stack_f32": (_i, [_vp, _c.POINTER(ConvLayer), _i, _vp, _vp, _sz, _i, _i, _vp]),
     "aligner_forward_sum_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_forward_sum_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_forward_sum_ctc_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -25,7 +25,14 @@
 //    below are exact), one raw s_barrier per chunk: nothing in the loop drains the memory queue.
 //  * Two workgroups per CU (2 x 56 KB LDS, <= 256 VGPRs): one wave's barrier / wait is the other's matrix time.
 //  * Output orientation: frames are the MFMA's M axis, so a lane holds 4 consecutive frames of one output channel:
-//    16-byte stores into [B, Cout, T].
+//    16-byte stores into [B, Cout, T] -- or, when the next layer of the stack is a k = 1 convolution, the operands swap
+//    roles (output channels on the M axis: a lane holds 4 consecutive channels of one frame) and the epilogue writes
+//    the NEXT layer's split channels-last fragments directly (8-byte stores): a stack costs one split pass, for its
+//    first layer only.
+//  * Narrow layers (fewer than 128 output channels: the mel encoder, the projections down to the attention
+//    channels) turn the roles around -- conv_narrow_kernel: every wave owns ALL frames of the workgroup's tile and
+//    16 or 32 output channels; the activations of ALL input chunks are staged at once (one barrier, no ring: these
+//    layers are bound by HBM, not by the matrix cores), the weight fragments stream through a four-step register ring.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -129,17 +136,22 @@ struct ConvGemmParams {
     const uint4 *xs;        // split activations, plane 0 (plane 1 at + xs_plane)
     const uint4 *wp;        // prepared weights
     const float *bias;      // nullable
-    float *y;               // [B, Cout, T]
-    unsigned long long xs_plane;
+    float *y;               // [B, Cout, T] fp32 output (SPLIT = false)
+    uint4 *ys;              // SPLIT: the next (k = 1) layer's split activations, plane 0
+    unsigned long long xs_plane, ys_plane;
     int B, Cout, T, S, nch, cpad, relu, nx;
+    int S2, nch2;           // SPLIT: slots per row and 32-channel chunks of the next layer's image
 };
 
+#ifndef CG_DMA_BITS
+#define CG_DMA_BITS ""
+#endif
 // ---- hand-issued memory operations (the compiler neither counts nor waits for them: every wait below is ours) ----
 // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses (sbase + voff) to LDS [lds_dst + 16*lane]
 __device__ __forceinline__ void cg_dma16(unsigned lds_dst, unsigned voff, const void *sbase) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 "global_load_lds_dwordx4 %1, %2 " CG_DMA_BITS "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 template <int OFF>
@@ -150,10 +162,94 @@ template <int CNT>
 __device__ __forceinline__ void cg_wait4(cg_u32x4 &a, cg_u32x4 &b, cg_u32x4 &c, cg_u32x4 &d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT) : "memory");
 }
+template <int CNT>
+__device__ __forceinline__ void cg_wait2(cg_u32x4 &a, cg_u32x4 &b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(CNT) : "memory");
+}
 
-template <int KT, int FT>
+// ---- epilogues, shared by both kernels: NT output-channel tiles x FT frame tiles of 16x16 accumulators ----
+// fp32 [B, Cout, T]: the accumulators were built with frames on the M axis (mfma(x, w)): column = lane & 15 is the
+// output channel, rows 4*(lane >> 4) + r are consecutive frames -> one 16-byte store per tile
+template <int NT, int FT>
+__device__ __forceinline__ void cg_store_f32(const ConvGemmParams &p, const cg_f32x4 (&acc)[NT][FT], int b, int otile0, int f0,
+                                             int lane) {
+    const int q = lane >> 4, j16 = lane & 15;
+    const bool vec = (p.T & 3) == 0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const int o = 16 * (otile0 + a) + j16;
+        if (o >= p.Cout) continue;
+        const float bv = p.bias ? p.bias[o] : 0.f;
+        float *yr = p.y + ((size_t)b * p.Cout + o) * p.T;
+#pragma unroll
+        for (int n = 0; n < FT; ++n) {
+            const int f = f0 + 16 * n + 4 * q;
+            cg_f32x4 v = acc[a][n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] += bv;
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (vec) {
+                if (f < p.T) *reinterpret_cast<cg_f32x4 *>(yr + f) = v;       // T % 4 == 0: a quad is all in or all out
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (f + r < p.T) yr[f + r] = v[r];
+            }
+        }
+    }
+}
+// the next layer's split image (that layer has k = 1: no halo, slot = frame): the accumulators were built with output
+// channels on the M axis (mfma(w, x)): column = lane & 15 is the frame, rows 4*(lane >> 4) + r are consecutive output
+// channels = half of one 16-byte fragment (8 channels) -> one 8-byte store per plane and tile; lanes q and q ^ 1 fill
+// the two halves of a fragment, 16 consecutive frames are 256 bytes in a row.  Frames >= T inside the tile and
+// channels >= Cout (zero weights, no bias) are written as zeros: the consumer's padding is data.
+template <int NT, int FT>
+__device__ __forceinline__ void cg_store_split(const ConvGemmParams &p, const cg_f32x4 (&acc)[NT][FT], int b, int otile0, int f0,
+                                               int lane) {
+    const int q = lane >> 4, j16 = lane & 15;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const int ob = 16 * (otile0 + a) + 4 * q;                            // this lane's 4 channels: ob .. ob+3
+        if (ob >= 32 * p.nch2) continue;                                     // (a tile past the consumer's last chunk)
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (p.bias && ob + r < p.Cout) ? p.bias[ob + r] : 0.f;
+        // image [b][chunk = ob / 32][quarter = (ob % 32) / 8][slot] of 16 bytes; this lane's half at + 8 * ((ob % 8) / 4)
+        const size_t row = (((size_t)b * p.nch2 + (ob >> 5)) * 4 + ((ob & 31) >> 3)) * p.S2;
+        unsigned char *dst0 = reinterpret_cast<unsigned char *>(p.ys + row) + 8 * ((ob & 7) >> 2);
+#pragma unroll
+        for (int n = 0; n < FT; ++n) {
+            const int f = f0 + 16 * n + j16;
+            if (f >= p.S2) continue;
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[a][n][r] + bv[r];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (f >= p.T || ob + r >= p.Cout) v = 0.f;
+                __bf16 hh, ll;
+                cg_split(v, hh, ll);
+                hv[r] = hh;
+                lv[r] = ll;
+            }
+            unsigned char *d = dst0 + (size_t)f * 16;
+            *reinterpret_cast<bf16x4 *>(d) = hv;
+            *reinterpret_cast<bf16x4 *>(d + p.ys_plane * 16) = lv;
+        }
+    }
+}
+
+// 6 MFMAs of one (frame tile, output tile pair): products lo*hi, hi*lo, hi*hi; SPLIT swaps the operands' roles
+template <bool SPLIT>
+__device__ __forceinline__ cg_f32x4 cg_mfma(cg_bf16x8 x, cg_bf16x8 w, cg_f32x4 c) {
+    return SPLIT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, w, c, 0, 0, 0);
+}
+
+template <int KT, int FT, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
-    constexpr int HALO = KT / 2;
     constexpr int LROW = cg_lrow(KT, FT);             // LDS slots per (plane, quarter) row: >= 16*FT + 2*HALO, multiple of 32
     constexpr int NSLOT = 8 * LROW;                   // per stage: 2 planes x 4 channel quarters
     constexpr int STAGE = NSLOT * 16;                 // bytes
@@ -243,12 +339,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
                     nh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * (n + 1) + t) * 16);
                     nl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * (n + 1) + t) * 16);
                 }
-                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh0, acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh1, acc[1][n], 0, 0, 0);
-                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl0, acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl1, acc[1][n], 0, 0, 0);
-                acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh0, acc[0][n], 0, 0, 0);
-                acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh1, acc[1][n], 0, 0, 0);
+                acc[0][n] = cg_mfma<SPLIT>(xl, wh0, acc[0][n]);
+                acc[1][n] = cg_mfma<SPLIT>(xl, wh1, acc[1][n]);
+                acc[0][n] = cg_mfma<SPLIT>(xh, wl0, acc[0][n]);
+                acc[1][n] = cg_mfma<SPLIT>(xh, wl1, acc[1][n]);
+                acc[0][n] = cg_mfma<SPLIT>(xh, wh0, acc[0][n]);
+                acc[1][n] = cg_mfma<SPLIT>(xh, wh1, acc[1][n]);
                 // 2 reads, then 6 MFMAs: keep this tile's reads (for the next tile) ahead of this tile's MFMAs
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS read
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);          // MFMA
@@ -263,95 +359,315 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWL) : "memory");         // the next chunk's staging pieces have landed
         __builtin_amdgcn_s_barrier();                                        // everybody's; and this chunk's stage is free
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (the clamped re-loads of the last chunk)
+    // the clamped re-loads of the last chunk are still in flight INTO W: the wait names every register of the ring, or
+    // hipcc -- for whom they are dead after the last MFMA -- reuses them in the epilogue under the landing loads
+#pragma unroll
+    for (int t = 0; t < KT; ++t) cg_wait4<0>(W[t][0], W[t][1], W[t][2], W[t][3]);
 
-    // epilogue.  C/D layout of 16x16: column = lane & 15 (output channel), rows 4*(lane >> 4) + r (frames)
-    const bool vec = (p.T & 3) == 0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int o = o0 + 32 * wave + 16 * a + j16;
-        if (o >= p.Cout) continue;
-        const float bv = p.bias ? p.bias[o] : 0.f;
-        float *yr = p.y + ((size_t)b * p.Cout + o) * p.T;
-#pragma unroll
-        for (int n = 0; n < FT; ++n) {
-            const int f = f0 + 16 * n + 4 * q;
-            cg_f32x4 v = acc[a][n];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] += bv;
-                if (p.relu) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (vec) {
-                if (f < p.T) *reinterpret_cast<cg_f32x4 *>(yr + f) = v;       // T % 4 == 0: a quad is all in or all out
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (f + r < p.T) yr[f + r] = v[r];
-            }
-        }
-    }
+    if (SPLIT) cg_store_split<2, FT>(p, acc, b, o0 / 16 + 2 * wave, f0, lane);
+    else       cg_store_f32<2, FT>(p, acc, b, o0 / 16 + 2 * wave, f0, lane);
 }
 
-template <int KT, int FT>
+// ---- narrow layers: Cout <= 256 (in practice the 80 / 160 channels of the mel encoder and the attention projections) ----
+// A workgroup = NW waves = one utterance's 16*FT frames x ALL output channels; wave w owns output tiles NT*w .. NT*w+NT-1
+// (16 channels each) and every frame tile.  The activations of ALL chunks are staged at once (LDS image
+// [chunk][plane][quarter][slot]): these layers have 3 to 32 chunks of a few hundred MFMA cycles each -- a ring with a
+// barrier per chunk would be all latency; what overlaps staging and arithmetic here is the other workgroup of the CU.
+// The weight fragments stream through a ring of four (chunk, tap) steps in registers, as in the wide kernel.
+constexpr int CN_RING = 4;
+template <int KT, int FT, int NT, bool SPLIT>
+__global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
+    constexpr int LROW = cg_lrow(KT, FT);
+    constexpr int CHSLOT = 8 * LROW;                  // slots per chunk: 2 planes x 4 quarters
+    constexpr int NWL = 2 * NT;                       // weight fragment loads per wave and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int q = lane >> 4, j16 = lane & 15;
+    const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
+    const int f0 = bx * 16 * FT;
+    const int nch = p.nch;
+
+    // ---- stage every chunk: piece = 64 consecutive LDS slots, dealt round-robin to the waves ----
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xs + (size_t)b * nch * 4 * p.S);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
+    const int npiece = nch * CHSLOT / 64;
+    for (int pc = wave; pc < npiece; pc += nw) {
+        const int i = 64 * pc + lane;
+        const int c = i / CHSLOT, r = i - c * CHSLOT;
+        const int plane = r / (4 * LROW), qq = (r / LROW) & 3, s = r % LROW;
+        const unsigned voff = (unsigned)(((size_t)plane * p.xs_plane + ((size_t)c * 4 + qq) * p.S + f0 + s) * 16);
+        cg_dma16(lds0 + (unsigned)pc * 1024u, voff, xbase);
+    }
+    // ---- weights: ring of CN_RING steps, step s = chunk * KT + tap, this wave's NT tiles x 2 planes in a row ----
+    const int nstep = nch * KT;
+    const unsigned wvoff = (unsigned)lane * 16u + (unsigned)(NT * wave * 2) * 1024u;
+    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wp);
+    const size_t wstep = (size_t)(p.cpad / 16) * 2 * 1024;
+    cg_u32x4 W[CN_RING][2 * NT];
+    auto load_w = [&](int s, cg_u32x4 (&w)[2 * NT]) {
+        const unsigned char *sb = wbase + (size_t)(s < nstep ? s : nstep - 1) * wstep;   // clamped: the counts stay exact
+        cg_wload<0>(w[0], wvoff, sb);
+        cg_wload<1024>(w[1], wvoff, sb);
+        if (NT == 2) {
+            cg_wload<2048>(w[2 * NT - 2], wvoff, sb);
+            cg_wload<3072>(w[2 * NT - 1], wvoff, sb);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < CN_RING; ++i) load_w(i, W[i]);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * NWL) : "memory");   // this wave's staging pieces have landed ...
+    __builtin_amdgcn_s_barrier();                                            // ... and everybody's
+
+    cg_f32x4 acc[NT][FT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int n = 0; n < FT; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lbase = (unsigned)(q * LROW + j16) * 16u;
+
+    for (int s0 = 0; s0 < nstep; s0 += CN_RING) {
+#pragma unroll
+        for (int i = 0; i < CN_RING; ++i) {
+            const int s = s0 + i;
+            if (NT == 2) cg_wait4<(CN_RING - 1) * NWL>(W[i][0], W[i][1], W[i][2], W[i][3]);
+            else         cg_wait2<(CN_RING - 1) * NWL>(W[i][0], W[i][1]);
+            if (s < nstep) {                                                 // (uniform; only the last group is partial)
+                const int c = s / KT, t = s - c * KT;
+                const unsigned char *st = cg_smem + (size_t)c * CHSLOT * 16 + lbase + t * 16;
+                const cg_bf16x8 wh0 = __builtin_bit_cast(cg_bf16x8, W[i][0]), wl0 = __builtin_bit_cast(cg_bf16x8, W[i][1]);
+                const cg_bf16x8 wh1 = __builtin_bit_cast(cg_bf16x8, W[i][2 * NT - 2]), wl1 = __builtin_bit_cast(cg_bf16x8, W[i][2 * NT - 1]);
+#pragma unroll
+                for (int n = 0; n < FT; ++n) {
+                    const cg_bf16x8 xh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * n) * 16);
+                    const cg_bf16x8 xl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * n) * 16);
+                    acc[0][n] = cg_mfma<SPLIT>(xl, wh0, acc[0][n]);
+                    acc[0][n] = cg_mfma<SPLIT>(xh, wl0, acc[0][n]);
+                    acc[0][n] = cg_mfma<SPLIT>(xh, wh0, acc[0][n]);
+                    if (NT == 2) {
+                        acc[NT - 1][n] = cg_mfma<SPLIT>(xl, wh1, acc[NT - 1][n]);
+                        acc[NT - 1][n] = cg_mfma<SPLIT>(xh, wl1, acc[NT - 1][n]);
+                        acc[NT - 1][n] = cg_mfma<SPLIT>(xh, wh1, acc[NT - 1][n]);
+                    }
+                }
+            }
+            asm volatile("" : "+v"(acc[0][FT - 1]), "+v"(acc[NT - 1][FT - 1]));
+            __builtin_amdgcn_sched_barrier(0);
+            load_w(s + CN_RING, W[i]);
+        }
+    }
+    // the clamped re-loads of the last steps are still in flight INTO the ring's registers: the wait names every one of
+    // them, or hipcc -- for whom they are dead after the last MFMA -- hands them to the epilogue's first instructions and
+    // the landing loads overwrite those (seen: a lane's channel index, i.e. stores to another wave's channels)
+#pragma unroll
+    for (int i = 0; i < CN_RING; ++i) {
+        if (NT == 2) cg_wait4<0>(W[i][0], W[i][1], W[i][2], W[i][3]);
+        else         cg_wait2<0>(W[i][0], W[i][1]);
+    }
+    if (SPLIT) cg_store_split<NT, FT>(p, acc, b, NT * wave, f0, lane);
+    else       cg_store_f32<NT, FT>(p, acc, b, NT * wave, f0, lane);
+}
+
+template <int KT, int FT, bool SPLIT>
 static int launch_conv_gemm(const ConvGemmParams &p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 8 * cg_lrow(KT, FT) * 16;
-    auto kern = conv_gemm_kernel<KT, FT>;
+    auto kern = conv_gemm_kernel<KT, FT, SPLIT>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     const unsigned grid = (unsigned)p.nx * (unsigned)(p.cpad / CG_TO) * (unsigned)p.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
-
-// ---- what softattn.hip's entry points call ----
-bool conv_gemm_applies(int Cin, int Cout, int K) {
-    // wide layers only: >= one full workgroup of output channels and enough input channels to amortise the pipeline;
-    // the narrow mel / projection layers keep conv1d_prepared_kernel
-    return Cout >= 128 && Cin >= 64 && (K == 1 || K == 3 || K == 5);
-}
-size_t conv_gemm_prepared_bytes(int Cout, int Cin, int K) { return conv_gemm_layout(1, Cin, Cout, 16, K).w_bytes; }
-size_t conv_gemm_workspace_bytes(int B, int Cin, int Cout, int T, int K) { return conv_gemm_layout(B, Cin, Cout, T, K).xs_bytes; }
-
-int conv_gemm_prepare(const float *w, void *prepared, int Cout, int Cin, int K, hipStream_t s) {
-    const ConvGemmLayout L = conv_gemm_layout(1, Cin, Cout, 16, K);
-    const int nfrag = L.nch * K * (L.cpad / 16) * 64;
-    hipLaunchKernelGGL(conv_gemm_wprep_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, s, w, static_cast<uint4 *>(prepared),
-                       Cout, Cin, K, L.cpad, nfrag);
+template <int KT, int FT, int NT, bool SPLIT>
+static int launch_conv_narrow(const ConvGemmParams &p, int nw, hipStream_t s) {
+    const size_t lds = (size_t)p.nch * 8 * cg_lrow(KT, FT) * 16;
+    auto kern = conv_narrow_kernel<KT, FT, NT, SPLIT>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)p.B), dim3(64 * nw), lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
 
+// ---- host side: which form a layer takes, its prepared weights, its launch ----
+enum { CG_NONE = 0, CG_WIDE = 1, CG_NARROW = 2 };
+struct ConvPlan { int form, FT, NT, nw, nx, cpad; size_t lds; };
+
+static int conv_form(int Cin, int Cout, int K) {
+    if (K != 1 && K != 3 && K != 5) return CG_NONE;
+    if (Cout >= 128 && Cin >= 64) return CG_WIDE;
+    if (Cout <= 256 && Cin >= 16) return CG_NARROW;
+    return CG_NONE;
+}
+static int conv_cpad(int form, int Cout) { return form == CG_WIDE ? (Cout + 127) / 128 * 128 : (Cout + 31) / 32 * 32; }
+
+static ConvPlan conv_plan(int B, int Cin, int Cout, int T, int K) {
+    ConvPlan P{conv_form(Cin, Cout, K), 0, 0, 0, 0, 0, 0};
+    if (P.form == CG_NONE) return P;
+    P.cpad = conv_cpad(P.form, Cout);
+    const int nch = (Cin + CG_CH - 1) / CG_CH;
+    if (P.form == CG_WIDE) {
+        // frames per workgroup: one utterance's whole T when it fits 13 tiles of 16 (T = 200 -> 208), else the tile count
+        // that wastes least
+        P.FT = 13;
+        if (T > 16 * 13) {
+            const int w13 = (T + 207) / 208 * 208, w8 = (T + 127) / 128 * 128;
+            P.FT = w8 < w13 ? 8 : 13;
+        } else if (T <= 128) {
+            P.FT = 8;
+        }
+        P.NT = 2; P.nw = 4;
+        P.lds = (size_t)2 * 8 * cg_lrow(K, P.FT) * 16;
+    } else {
+        // output tiles per wave: 32 channels from 144 output channels on (at most 8 waves); frames per workgroup: the
+        // largest tile that still gives the chip two workgroups per CU and whose activations fit in LDS
+        P.NT = P.cpad > 128 ? 2 : 1;
+        P.nw = P.cpad / (16 * P.NT);
+        const size_t lds_max = (size_t)device_lds_limit();
+        const int cus = device_cu_count();
+        for (int ft : {8, 4, 2}) {                                           // descending: the first that fills the chip,
+            if (g_opt_conv_narrow_ft && ft != g_opt_conv_narrow_ft) continue;   // testing: aligner_debug_set_option
+            const size_t lds = (size_t)nch * 8 * cg_lrow(K, ft) * 16;        // else the smallest that fits in LDS
+            if (lds > lds_max) continue;
+            P.FT = ft;
+            P.lds = lds;
+            if ((long long)((T + 16 * ft - 1) / (16 * ft)) * B >= 2LL * cus) break;
+        }
+        if (P.FT == 0) { P.form = CG_NONE; return P; }                       // too many input channels for one LDS
+    }
+    P.nx = (T + 16 * P.FT - 1) / (16 * P.FT);
+    return P;
+}
+
+static int conv_launch(const ConvPlan &P, ConvGemmParams &p, int K, bool split, hipStream_t s) {
+    p.nx = P.nx;
+    p.cpad = P.cpad;
+    if ((unsigned long long)p.nx * (p.cpad / 16) * p.B >= (1ull << 31)) return fail(ALIGNER_EDOM, "grid too large");
+#define CG_W(KT, FT) (split ? launch_conv_gemm<KT, FT, true>(p, s) : launch_conv_gemm<KT, FT, false>(p, s))
+#define CG_N(KT, FT, NT) (split ? launch_conv_narrow<KT, FT, NT, true>(p, P.nw, s) : launch_conv_narrow<KT, FT, NT, false>(p, P.nw, s))
+#define CG_NF(KT, NT) (P.FT == 8 ? CG_N(KT, 8, NT) : P.FT == 4 ? CG_N(KT, 4, NT) : CG_N(KT, 2, NT))
+#define CG_NK(NT) (K == 1 ? CG_NF(1, NT) : K == 3 ? CG_NF(3, NT) : CG_NF(5, NT))
+    if (P.form == CG_WIDE) {
+        if (K == 1) return P.FT == 13 ? CG_W(1, 13) : CG_W(1, 8);
+        if (K == 3) return P.FT == 13 ? CG_W(3, 13) : CG_W(3, 8);
+        return P.FT == 13 ? CG_W(5, 13) : CG_W(5, 8);
+    }
+    return P.NT == 2 ? CG_NK(2) : CG_NK(1);
+#undef CG_W
+#undef CG_N
+#undef CG_NF
+#undef CG_NK
+}
+
+// ---- what softattn.hip's entry points call ----
+bool conv_gemm_applies(int Cin, int Cout, int K) { return conv_form(Cin, Cout, K) != CG_NONE; }
+
+size_t conv_gemm_prepared_bytes(int Cout, int Cin, int K) {
+    const int form = conv_form(Cin, Cout, K);
+    if (form == CG_NONE) return 0;
+    const int nch = (Cin + CG_CH - 1) / CG_CH;
+    return (size_t)nch * K * (conv_cpad(form, Cout) / 16) * 2 * 64 * sizeof(uint4);
+}
+
+int conv_gemm_prepare(const float *w, void *prepared, int Cout, int Cin, int K, hipStream_t s) {
+    const int form = conv_form(Cin, Cout, K);
+    const int cpad = conv_cpad(form, Cout), nch = (Cin + CG_CH - 1) / CG_CH;
+    const int nfrag = nch * K * (cpad / 16) * 64;
+    hipLaunchKernelGGL(conv_gemm_wprep_kernel, dim3((nfrag + 255) / 256), dim3(256), 0, s, w, static_cast<uint4 *>(prepared),
+                       Cout, Cin, K, cpad, nfrag);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+// A stack of layers y = act(conv(...act(conv(x)))) on split activations.  Workspace: two split images that take turns
+// (each sized for the largest one of the stack) + an fp32 temporary for a layer whose consumer is not a k = 1 layer
+// of one of these forms.  Returns the index of the first layer the stack runner cannot take (== n: all of them).
+struct ConvStackLayer { const void *prepared; const float *bias; int Cin, Cout, K, relu; };
+
+static size_t split_image_bytes(int B, int Cin, int T, int K) {
+    const size_t nch = (Cin + CG_CH - 1) / CG_CH, S = (T + 2 * (K / 2) + 15) / 16 * 16;
+    return align_up((2 * (size_t)B * nch * 4 * S + 512) * sizeof(uint4), 256);
+}
+
+size_t conv_stack_workspace_bytes(const ConvStackLayer *L, int n, int B, int T) {
+    size_t img = 0, tmp = 0;
+    for (int i = 0; i < n; ++i) {
+        if (conv_plan(B, L[i].Cin, L[i].Cout, T, L[i].K).form == CG_NONE) return 0;
+        const size_t v = split_image_bytes(B, L[i].Cin, T, L[i].K);
+        img = v > img ? v : img;
+        if (i + 1 < n && L[i + 1].K != 1) {
+            const size_t t = align_up((size_t)B * L[i].Cout * T * sizeof(float), 256);
+            tmp = t > tmp ? t : tmp;
+        }
+    }
+    return 2 * img + tmp;
+}
+
+int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, void *workspace, size_t workspace_bytes, int B, int T,
+                   hipStream_t s) {
+    const size_t need = conv_stack_workspace_bytes(L, n, B, T);
+    if (need == 0) return fail(ALIGNER_EDOM, "a layer of this stack has no GEMM form");
+    if (workspace_bytes < need) return fail(ALIGNER_ENOSPC, "conv workspace %zu < %zu bytes", workspace_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(ALIGNER_EINVAL, "conv workspace must be 16-byte aligned");
+    size_t img = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t v = split_image_bytes(B, L[i].Cin, T, L[i].K);
+        img = v > img ? v : img;
+    }
+    if (img >= (1ull << 32)) return fail(ALIGNER_EDOM, "split activations of %zu bytes exceed 32-bit offsets", img);
+    unsigned char *wsb = static_cast<unsigned char *>(workspace);
+    uint4 *bufs[2] = {reinterpret_cast<uint4 *>(wsb), reinterpret_cast<uint4 *>(wsb + img)};
+    float *tmp = reinterpret_cast<float *>(wsb + 2 * img);
+    auto split_pass = [&](const float *src, uint4 *dst, int Cin, int K) -> int {
+        const size_t nch = (Cin + CG_CH - 1) / CG_CH, S = (T + 2 * (K / 2) + 15) / 16 * 16;
+        const size_t plane = (size_t)B * nch * 4 * S;
+        hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, Cin, T, (int)S,
+                           (int)nch, K / 2, plane);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        return ALIGNER_OK;
+    };
+    int cur = 0;
+    int rc = split_pass(x, bufs[0], L[0].Cin, L[0].K);
+    if (rc != ALIGNER_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        const ConvPlan P = conv_plan(B, L[i].Cin, L[i].Cout, T, L[i].K);
+        const int nch = (L[i].Cin + CG_CH - 1) / CG_CH, S = (T + 2 * (L[i].K / 2) + 15) / 16 * 16;
+        const bool last = i + 1 == n;
+        const bool split = !last && L[i + 1].K == 1;                         // write the consumer's image directly
+        ConvGemmParams p{};
+        p.xs = bufs[cur]; p.wp = static_cast<const uint4 *>(L[i].prepared); p.bias = L[i].bias;
+        p.xs_plane = (unsigned long long)B * nch * 4 * S;
+        p.B = B; p.Cout = L[i].Cout; p.T = T; p.S = S; p.nch = nch; p.relu = L[i].relu;
+        if (split) {
+            p.nch2 = (L[i].Cout + CG_CH - 1) / CG_CH;
+            p.S2 = (T + 15) / 16 * 16;
+            p.ys = bufs[cur ^ 1];
+            p.ys_plane = (unsigned long long)B * p.nch2 * 4 * p.S2;
+        } else {
+            p.y = last ? y : tmp;
+        }
+        rc = conv_launch(P, p, L[i].K, split, s);
+        if (rc != ALIGNER_OK) return rc;
+        if (getenv("ALIGNER_CONV_SYNC")) (void)hipStreamSynchronize(s);
+        if (split) {
+            cur ^= 1;
+        } else if (!last) {
+            rc = split_pass(tmp, bufs[cur], L[i + 1].Cin, L[i + 1].K);     // (this layer has read bufs[cur]: stream order)
+            if (rc != ALIGNER_OK) return rc;
+        }
+    }
+    return ALIGNER_OK;
+}
+
+size_t conv_gemm_workspace_bytes(int B, int Cin, int Cout, int T, int K) {
+    ConvStackLayer l{nullptr, nullptr, Cin, Cout, K, 0};
+    return conv_stack_workspace_bytes(&l, 1, B, T);
+}
+
 int conv_gemm_run(const float *x, const void *prepared, const float *bias, float *y, void *workspace, size_t workspace_bytes,
                   int B, int Cin, int Cout, int T, int K, int relu, hipStream_t s) {
-    const ConvGemmLayout L = conv_gemm_layout(B, Cin, Cout, T, K);
-    if (workspace_bytes < L.xs_bytes) return fail(ALIGNER_ENOSPC, "conv workspace %zu < %zu bytes", workspace_bytes, L.xs_bytes);
-    if (L.xs_bytes >= (1ull << 32)) return fail(ALIGNER_EDOM, "split activations of %zu bytes exceed 32-bit offsets", L.xs_bytes);
-    if (reinterpret_cast<uintptr_t>(workspace) & 15) return fail(ALIGNER_EINVAL, "conv workspace must be 16-byte aligned");
-    uint4 *xs = static_cast<uint4 *>(workspace);
-    const size_t total = L.xs_plane;
-    hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, xs, L.xs_plane, Cin, T, L.S,
-                       L.nch, K / 2, total);
-    ALIGNER_HIP_CHECK(hipGetLastError());
-    ConvGemmParams p{xs, static_cast<const uint4 *>(prepared), bias, y, (unsigned long long)L.xs_plane, B, Cout, T, L.S, L.nch,
-                     L.cpad, relu, 1};
-    // frames per workgroup: one utterance's whole T when it fits 13 tiles of 16 (T = 200 -> 208), else the tile count that
-    // wastes least
-    int FT = 13;
-    if (T > 16 * 13) {
-        const int w13 = (T + 207) / 208 * 208, w8 = (T + 127) / 128 * 128;
-        FT = w8 < w13 ? 8 : 13;
-    } else if (T <= 128) {
-        FT = 8;
-    }
-    p.nx = (T + 16 * FT - 1) / (16 * FT);
-    if ((unsigned long long)p.nx * (L.cpad / CG_TO) * B >= (1ull << 31)) return fail(ALIGNER_EDOM, "grid too large");
-#define CG_LAUNCH(KT)                                                              \
-    return FT == 13 ? launch_conv_gemm<KT, 13>(p, s) : launch_conv_gemm<KT, 8>(p, s)
-    if (K == 1) { CG_LAUNCH(1); }
-    if (K == 3) { CG_LAUNCH(3); }
-    CG_LAUNCH(5);
-#undef CG_LAUNCH
+    ConvStackLayer l{prepared, bias, Cin, Cout, K, relu};
+    return conv_stack_run(x, &l, 1, y, workspace, workspace_bytes, B, T, s);
 }
 
 }  // namespace aligner

@@ -43,6 +43,10 @@ size_t conv_gemm_workspace_bytes(int B, int Cin, int Cout, int T, int K);
 int conv_gemm_prepare(const float *w, void *prepared, int Cout, int Cin, int K, hipStream_t s);
 int conv_gemm_run(const float *x, const void *prepared, const float *bias, float *y, void *workspace, size_t workspace_bytes,
                   int B, int Cin, int Cout, int T, int K, int relu, hipStream_t s);
+struct ConvStackLayer { const void *prepared; const float *bias; int Cin, Cout, K, relu; };
+size_t conv_stack_workspace_bytes(const ConvStackLayer *L, int n, int B, int T);
+int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, void *workspace, size_t workspace_bytes, int B, int T,
+                   hipStream_t s);
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -1602,12 +1606,49 @@ int aligner_conv1d_prepared_ws_f32(const float *x, const void *prepared, const f
     if (K != 1 && K != 3 && K != 5) return fail(ALIGNER_EDOM, "kernel size %d not supported (1, 3, 5)", K);
     if (B == 0) return ALIGNER_OK;
     static const bool no_gemm = [] { const char *e = getenv("ALIGNER_CONV_NO_GEMM"); return e && e[0] == '1'; }();
-    if (!conv_gemm_applies(Cin, Cout, K) || no_gemm)      // narrow layers: conv1d_prepared_kernel, no workspace needed
+    const size_t nws = (conv_gemm_applies(Cin, Cout, K) && !no_gemm) ? conv_gemm_workspace_bytes(B, Cin, Cout, T, K) : 0;
+    if (nws == 0)                                          // no GEMM form for this layer: conv1d_prepared_kernel, no workspace
         return aligner_conv1d_prepared_f32(x, prepared, bias, y, B, Cin, Cout, T, K, relu, stream);
     if (!workspace) return fail(ALIGNER_EINVAL, "this layer needs aligner_conv1d_workspace_bytes() of workspace");
     const unsigned char *pp = static_cast<const unsigned char *>(prepared);
     return conv_gemm_run(x, pp + conv_prep_first_bytes(Cout, Cin, K), bias, y, workspace, workspace_bytes, B, Cin, Cout, T, K,
                          relu, static_cast<hipStream_t>(stream));
+}
+
+// A whole encoder stack in one call: the first layer's input is split once, every k = 1 layer reads the image its
+// producer's epilogue wrote (no fp32 round trip between layers), the last layer writes fp32 [B, Cout, T].
+static int conv_stack_convert(const aligner_conv_layer *layers, int n, ConvStackLayer *L) {
+    for (int i = 0; i < n; ++i) {
+        const aligner_conv_layer &a = layers[i];
+        if (a.Cin < 1 || a.Cout < 1 || (a.K != 1 && a.K != 3 && a.K != 5)) return fail(ALIGNER_EINVAL, "layer %d: bad shape", i);
+        if (i > 0 && a.Cin != layers[i - 1].Cout) return fail(ALIGNER_EINVAL, "layer %d: %d input channels after %d outputs", i, a.Cin, layers[i - 1].Cout);
+        const unsigned char *pp = static_cast<const unsigned char *>(a.prepared);
+        L[i] = ConvStackLayer{pp ? pp + conv_prep_first_bytes(a.Cout, a.Cin, a.K) : nullptr, a.bias, a.Cin, a.Cout, a.K, a.relu};
+    }
+    return ALIGNER_OK;
+}
+
+size_t aligner_conv_stack_workspace_bytes(const aligner_conv_layer *layers, int n_layers, int B, int T) {
+    if (!layers || n_layers < 1 || n_layers > 16 || B < 1 || T < 1) return 0;
+    ConvStackLayer L[16];
+    if (conv_stack_convert(layers, n_layers, L) != ALIGNER_OK) return 0;
+    for (int i = 0; i < n_layers; ++i)
+        if (!conv_gemm_applies(L[i].Cin, L[i].Cout, L[i].K)) return 0;
+    return conv_stack_workspace_bytes(L, n_layers, B, T);
+}
+
+int aligner_conv_stack_f32(const float *x, const aligner_conv_layer *layers, int n_layers, float *y, void *workspace,
+                           size_t workspace_bytes, int B, int T, void *stream) {
+    if (!x || !layers || !y || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (n_layers < 1 || n_layers > 16) return fail(ALIGNER_EINVAL, "1..16 layers");
+    if (B < 0 || T < 1) return fail(ALIGNER_EINVAL, "bad shape");
+    if (B == 0) return ALIGNER_OK;
+    ConvStackLayer L[16];
+    const int rc = conv_stack_convert(layers, n_layers, L);
+    if (rc != ALIGNER_OK) return rc;
+    for (int i = 0; i < n_layers; ++i)
+        if (!layers[i].prepared) return fail(ALIGNER_EINVAL, "layer %d: null prepared weights", i);
+    return conv_stack_run(x, L, n_layers, y, workspace, workspace_bytes, B, T, static_cast<hipStream_t>(stream));
 }
 
 int aligner_conv1d_prepared_f32(const float *x, const void *prepared, const float *bias, float *y, int B, int Cin,

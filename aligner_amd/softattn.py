@@ -44,6 +44,29 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _prepared_weights(weight: torch.Tensor, device) -> torch.Tensor:
+    """weights -> split bf16 halves in the matrix cores' fragment order (aligner_conv1d_prepare_f32, a few
+    microseconds), kept per weight tensor (and stream: no cross-stream ordering) until the tensor is modified in place
+    (torch's version counter: the entry is then re-prepared in place, so a training loop does not grow the cache) or
+    replaced.  Updates that bypass the counter (`p.data.copy_()`, writes through a storage alias) are NOT seen: call
+    invalidate_prepared() after such an update."""
+    lib = _lib.load()
+    Cout, Cin, K = weight.shape
+    key = (weight.data_ptr(), Cout, Cin, K, device, _stream(device))
+    ent = _prepared.get(key)
+    if ent is None or ent[0] != weight._version:
+        nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
+        if nprep == 0:
+            raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
+        prep = ent[1] if ent is not None else torch.empty(nprep, dtype=torch.uint8, device=device)
+        _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K, _stream(device)))
+        if ent is None and len(_prepared) >= 256:
+            _prepared.pop(next(iter(_prepared)))       # oldest entry only
+        _prepared[key] = (weight._version, prep, weight)   # holding `weight` keeps its address from being reused
+        return prep
+    return ent[1]
+
+
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
     """y = act(conv1d(x, weight, bias, padding=K//2)); x [B,Cin,T], weight [Cout,Cin,K], K in {1,3,5}."""
     _lib.require_gpu()
@@ -56,27 +79,7 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     y = torch.empty((B, Cout, T), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     with torch.cuda.device(x.device):
-        # weights -> split bf16 halves in fragment order (a few microseconds), then the MFMA kernel.  The
-        # prepared form is kept per weight tensor until the tensor is modified in place (torch's version
-        # counter) or replaced.
-        # One entry per weight tensor (and stream: no cross-stream ordering); an in-place update bumps torch's
-        # version counter and the entry is re-prepared in place, so a training loop does not grow the cache.
-        # Updates that bypass the counter (`p.data.copy_()`, writes through a storage alias) are NOT seen:
-        # call invalidate_prepared() after such an update.
-        key = (weight.data_ptr(), Cout, Cin, K, x.device, _stream(x.device))
-        ent = _prepared.get(key)
-        if ent is None or ent[0] != weight._version:
-            nprep = lib.aligner_conv1d_prepared_bytes(Cout, Cin, K)
-            if nprep == 0:
-                raise ValueError(f"kernel size {K} not supported (1, 3, 5)")
-            prep = ent[1] if ent is not None else torch.empty(nprep, dtype=torch.uint8, device=x.device)
-            _lib.check(lib.aligner_conv1d_prepare_f32(weight.data_ptr(), prep.data_ptr(), nprep, Cout, Cin, K,
-                                                      _stream(x.device)))
-            if ent is None and len(_prepared) >= 256:
-                _prepared.pop(next(iter(_prepared)))   # oldest entry only
-            _prepared[key] = (weight._version, prep, weight)   # holding `weight` keeps its address from being reused
-        else:
-            prep = ent[1]
+        prep = _prepared_weights(weight, x.device)
         # wide layers split their activations into a workspace first (csrc/convgemm.hip); narrow ones need none
         nws = lib.aligner_conv1d_workspace_bytes(B, Cin, Cout, T, K)
         ws = _conv_workspaces.get(x.device, nws) if nws else None
@@ -179,6 +182,35 @@ class AlignmentEncoderParams:
 
 
 def encode(x: torch.Tensor, stack: List[Tuple[torch.Tensor, torch.Tensor]]) -> torch.Tensor:
+    """A conv stack (ReLU between the layers) -- in ONE call of the C ABI when every layer has a GEMM form
+    (aligner_conv_stack_f32: the input is split once, every k = 1 layer reads the split image its producer wrote; no fp32
+    round trip between layers), layer by layer otherwise."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    x = _chk(x, "x")
+    B, Cin, T = x.shape
+    dev = x.device
+    layers = (_lib.ConvLayer * len(stack))()
+    keep = []
+    c = Cin
+    with torch.cuda.device(dev):
+        for n, (w, b) in enumerate(stack):
+            w = _chk(w, "weight")
+            b = _chk(b, "bias") if b is not None else None
+            if w.shape[1] != c:
+                raise ValueError("channel mismatch")
+            prep = _prepared_weights(w, dev)
+            keep += [w, b, prep]
+            layers[n] = _lib.ConvLayer(prep.data_ptr(), None if b is None else b.data_ptr(), int(w.shape[1]), int(w.shape[0]),
+                                       int(w.shape[2]), int(n + 1 < len(stack)))
+            c = int(w.shape[0])
+        nws = lib.aligner_conv_stack_workspace_bytes(layers, len(stack), B, T) if B > 0 and len(stack) > 0 else 0
+        if nws:
+            y = torch.empty((B, c, T), dtype=torch.float32, device=dev)
+            ws = _conv_workspaces.get(dev, nws)
+            _lib.check(lib.aligner_conv_stack_f32(x.data_ptr(), layers, len(stack), y.data_ptr(), ws.data_ptr(), nws, B, T,
+                                                  _stream(dev)))
+            return y
     for n, (w, b) in enumerate(stack):
         x = conv1d(x, w, b, relu=(n + 1 < len(stack)))
     return x

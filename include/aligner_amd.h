@@ -291,17 +291,33 @@ int aligner_conv1d_prepared_f32(const float *x_dev, const void *prepared_dev, co
                                 float *y_dev, int B, int Cin, int Cout, int T, int K,
                                 int relu, void *stream);
 /*
- * ... and with a workspace, which the WIDE layers (Cout >= 128, Cin >= 64: the text encoder's 512 -> 1024 k=3) need for
- * their fast form: the activations are split into bf16 halves and transposed to channels-last fragments by a streaming
- * pass into the workspace (aligner_conv1d_workspace_bytes(B,Cin,Cout,T,K) bytes, 16-byte aligned; 0 = this layer needs
- * none), then a GEMM-structured kernel multiplies them with the prepared weights -- activations global -> LDS by
- * LDS-DMA, the weights' fragments straight into registers, nothing waited for inside the loop (csrc/convgemm.hip).
- * Narrow layers take the kernel of aligner_conv1d_prepared_f32 and ignore the workspace.  Same numerics as above.
+ * ... and with a workspace, which the fast form needs (csrc/convgemm.hip): the activations are split into bf16 halves
+ * and transposed to channels-last fragments by a streaming pass into the workspace
+ * (aligner_conv1d_workspace_bytes(B,Cin,Cout,T,K) bytes, 16-byte aligned; 0 = this layer has no such form and takes the
+ * kernel of aligner_conv1d_prepared_f32), then a GEMM-structured kernel multiplies them with the prepared weights --
+ * activations global -> LDS by LDS-DMA, the weights' fragments straight into registers, nothing waited for inside the
+ * loop.  Same numerics as above.
  */
 size_t aligner_conv1d_workspace_bytes(int B, int Cin, int Cout, int T, int K);
 int aligner_conv1d_prepared_ws_f32(const float *x_dev, const void *prepared_dev, const float *bias_dev,
                                    float *y_dev, void *workspace_dev, size_t workspace_bytes,
                                    int B, int Cin, int Cout, int T, int K, int relu, void *stream);
+
+/*
+ * A whole encoder stack y = conv_n(...act(conv_1(x))) in one call (the text / mel encoders of SURVEY.md 7.4): the first
+ * layer's input is split once, every k = 1 layer reads the split image its producer's epilogue wrote (no fp32 round trip
+ * between layers), the last layer writes fp32 [B, Cout_n, T].  layers[i].prepared = that layer's
+ * aligner_conv1d_prepare_f32 image; workspace aligner_conv_stack_workspace_bytes(...) bytes, 16-byte aligned
+ * (0: some layer has no GEMM form -- run the layers one by one through aligner_conv1d_prepared_ws_f32 instead).
+ */
+typedef struct aligner_conv_layer {
+    const void *prepared;       /* device: aligner_conv1d_prepare_f32(w, ..., Cout, Cin, K) */
+    const float *bias;          /* device, [Cout], nullable */
+    int Cin, Cout, K, relu;
+} aligner_conv_layer;
+size_t aligner_conv_stack_workspace_bytes(const aligner_conv_layer *layers, int n_layers, int B, int T);
+int aligner_conv_stack_f32(const float *x_dev, const aligner_conv_layer *layers, int n_layers, float *y_dev,
+                           void *workspace_dev, size_t workspace_bytes, int B, int T, void *stream);
 
 /*
  * Similarity -> log-softmax -> alignment search in ONE kernel (no reference

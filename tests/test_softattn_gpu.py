@@ -204,6 +204,13 @@ def test_conv1d_and_full_encoder(dev):
     (2, 96, 256, 900, 5, False),       # several frame tiles per utterance, k = 5 (two halo frames)
     (1, 256, 384, 129, 1, True),       # T just over 128: the 13-tile form with most of it empty
     (2, 70, 200, 1000, 3, True),       # 8-tile workgroups (1000 frames: 1024 vs 1040)
+    # narrow layers (conv_narrow_kernel: every wave all frames of the tile, activations of all chunks staged at once)
+    (3, 80, 160, 900, 3, True),        # mel encoder layer 1: 5 waves x 32 channels
+    (3, 160, 80, 900, 1, True),        # mel encoder layer 2: 5 waves x 16 channels
+    (2, 80, 80, 333, 1, False),        # T % 4 != 0, T % 16 != 0
+    (3, 1024, 80, 200, 1, False),      # text encoder projection: 32 chunks, 2 frame tiles per workgroup
+    (1, 33, 70, 129, 5, True),         # ragged everything, k = 5
+    (2, 16, 256, 40, 3, False),        # 8 waves x 32 channels, half a chunk of input
 ])
 def test_wide_conv_gemm_form(dev, B, Ci, Co, T, K, relu):
     """csrc/convgemm.hip (activations split + LDS-DMA staging + weight fragments in registers) against the fp32 oracle at
@@ -235,6 +242,39 @@ def test_wide_conv_gemm_form(dev, B, Ci, Co, T, K, relu):
     # no bias
     got = aligner_amd.conv1d(xd, wd, None, relu)
     assert (got.cpu() - S.conv1d(x, w, None, relu)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("B,T,chans,ks", [
+    (3, 200, (512, 1024, 80), (3, 1)),             # the text encoder of SURVEY 7.4
+    (3, 900, (80, 160, 80, 80), (3, 1, 1)),        # the mel encoder
+    (2, 150, (40, 64, 48, 130, 20), (5, 3, 3, 1)), # consumers with k != 1: fp32 temporary + split pass between the layers
+    (2, 77, (96, 300), (1,)),                      # one layer, 300 output channels (wide form, three output tiles)
+])
+def test_conv_stack_one_call(dev, B, T, chans, ks):
+    """aligner_conv_stack_f32 (encode()): the whole stack in one call, layers chained through split images, against the
+    fp32 oracle stack at 1e-4 and against the same layers run one by one."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from aligner_amd.softattn import encode
+    from oracle import softattn_oracle as S
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, chans[0], T, generator=g)
+    stack = []
+    for ci, co, k in zip(chans[:-1], chans[1:], ks):
+        stack.append((torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5, torch.randn(co, generator=g) * 0.1))
+    want = S.encode(x, stack)
+    dstack = [(w.to(dev), b.to(dev)) for w, b in stack]
+    lib = _lib.load()
+    layers = (_lib.ConvLayer * len(stack))(*[_lib.ConvLayer(None, None, w.shape[1], w.shape[0], w.shape[2], 0) for w, _ in stack])
+    assert lib.aligner_conv_stack_workspace_bytes(layers, len(stack), B, T) > 0, "this stack is meant to run as one call"
+    got = encode(x.to(dev), dstack)
+    torch.cuda.synchronize()
+    assert tuple(got.shape) == tuple(want.shape)
+    assert (got.cpu() - want).abs().max().item() < 1e-4
+    y = x.to(dev)
+    for n, (w, b) in enumerate(dstack):
+        y = aligner_amd.conv1d(y, w, b, relu=(n + 1 < len(dstack)))
+    assert (got - y).abs().max().item() < 5e-5
 
 
 def test_pipeline_similarity_then_dp(dev):
