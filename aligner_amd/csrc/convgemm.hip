@@ -495,7 +495,7 @@ struct ConvPlan { int form, FT, NT, nw, nx, cpad; size_t lds; };
 
 static int conv_form(int Cin, int Cout, int K) {
     if (K != 1 && K != 3 && K != 5) return CG_NONE;
-    if (Cout >= 128 && Cin >= 64) return CG_WIDE;
+    if (Cout >= 128 && Cin >= 128) return CG_WIDE;    // enough chunks to amortise the ring's prologue, full 128-channel tiles
     if (Cout <= 256 && Cin >= 16) return CG_NARROW;
     return CG_NONE;
 }
@@ -525,9 +525,13 @@ static ConvPlan conv_plan(int B, int Cin, int Cout, int T, int K) {
         P.nw = P.cpad / (16 * P.NT);
         const size_t lds_max = (size_t)device_lds_limit();
         const int cus = device_cu_count();
-        for (int ft : {8, 4, 2}) {                                           // descending: the first that fills the chip,
+        // Every workgroup streams ALL the layer's weights through its waves' registers, so frames per workgroup are
+        // weight reuse: the largest tile that fits in LDS and still gives the chip two workgroups per CU; a batch too small
+        // for that takes the smallest tile (most workgroups).  Measured at [64, ., 900]: 80 -> 80 k=1 13.2 us with 8-tile
+        // workgroups, 18.0 us with 2-tile ones.
+        for (int ft : {8, 4, 2}) {
             if (g_opt_conv_narrow_ft && ft != g_opt_conv_narrow_ft) continue;   // testing: aligner_debug_set_option
-            const size_t lds = (size_t)nch * 8 * cg_lrow(K, ft) * 16;        // else the smallest that fits in LDS
+            const size_t lds = (size_t)nch * 8 * cg_lrow(K, ft) * 16;
             if (lds > lds_max) continue;
             P.FT = ft;
             P.lds = lds;

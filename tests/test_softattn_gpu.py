@@ -199,11 +199,12 @@ def test_conv1d_and_full_encoder(dev):
 
 @pytest.mark.parametrize("B,Ci,Co,T,K,relu", [
     (3, 512, 1024, 200, 3, True),      # the C3 text encoder's wide layer: one 13-tile workgroup per utterance
-    (2, 64, 128, 16, 1, False),        # the smallest shape the GEMM form takes
-    (2, 100, 130, 201, 3, True),       # channels not a multiple of 32 / 128, T % 4 != 0 (scalar stores)
-    (2, 96, 256, 900, 5, False),       # several frame tiles per utterance, k = 5 (two halo frames)
+    (2, 128, 128, 16, 1, False),       # the smallest shape the wide form takes
+    (2, 130, 130, 201, 3, True),       # channels not a multiple of 32 / 128, T % 4 != 0 (scalar stores)
+    (2, 160, 256, 900, 5, False),      # several frame tiles per utterance, k = 5 (two halo frames)
     (1, 256, 384, 129, 1, True),       # T just over 128: the 13-tile form with most of it empty
-    (2, 70, 200, 1000, 3, True),       # 8-tile workgroups (1000 frames: 1024 vs 1040)
+    (2, 140, 200, 1000, 3, True),      # 8-tile workgroups (1000 frames: 1024 vs 1040)
+    (2, 64, 128, 16, 1, False),        # Cin < 128: the narrow form with 8 waves x 16 channels
     # narrow layers (conv_narrow_kernel: every wave all frames of the tile, activations of all chunks staged at once)
     (3, 80, 160, 900, 3, True),        # mel encoder layer 1: 5 waves x 32 channels
     (3, 160, 80, 900, 1, True),        # mel encoder layer 2: 5 waves x 16 channels
@@ -244,11 +245,36 @@ def test_wide_conv_gemm_form(dev, B, Ci, Co, T, K, relu):
     assert (got.cpu() - S.conv1d(x, w, None, relu)).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("ft", [8, 4, 2])
+def test_narrow_conv_every_frame_tile(dev, ft):
+    """conv_narrow_kernel's three tile sizes (the launch picks one from the batch size: small test batches would only
+    ever see the smallest), forced through the debug option, alone and chained."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from aligner_amd.softattn import encode
+    from oracle import softattn_oracle as S
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(ft)
+    try:
+        assert lib.aligner_debug_set_option(b"conv_narrow_ft", ft) == 0
+        for (B, T, chans, ks) in [(3, 333, (80, 160, 80, 80), (3, 1, 1)), (2, 200, (96, 48), (5,)), (5, 129, (160, 96, 33), (1, 1))]:
+            x = torch.randn(B, chans[0], T, generator=g)
+            stack = [(torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5, torch.randn(co, generator=g) * 0.1)
+                     for ci, co, k in zip(chans[:-1], chans[1:], ks)]
+            want = S.encode(x, stack)
+            for rep in range(3):                           # (the round-4 race showed in one run out of a few)
+                got = encode(x.to(dev), [(w.to(dev), b.to(dev)) for w, b in stack])
+                torch.cuda.synchronize()
+                assert (got.cpu() - want).abs().max().item() < 1e-4
+    finally:
+        lib.aligner_debug_set_option(b"conv_narrow_ft", 0)
+
+
 @pytest.mark.parametrize("B,T,chans,ks", [
     (3, 200, (512, 1024, 80), (3, 1)),             # the text encoder of SURVEY 7.4
     (3, 900, (80, 160, 80, 80), (3, 1, 1)),        # the mel encoder
     (2, 150, (40, 64, 48, 130, 20), (5, 3, 3, 1)), # consumers with k != 1: fp32 temporary + split pass between the layers
-    (2, 77, (96, 300), (1,)),                      # one layer, 300 output channels (wide form, three output tiles)
+    (2, 77, (160, 300), (1,)),                     # one layer, 300 output channels (wide form, three output tiles)
 ])
 def test_conv_stack_one_call(dev, B, T, chans, ks):
     """aligner_conv_stack_f32 (encode()): the whole stack in one call, layers chained through split images, against the

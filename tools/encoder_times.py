@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import aligner_amd
 from aligner_amd.softattn import encode
 dev = torch.device("cuda:0")
+from aligner_amd import _lib
+if os.environ.get("FT"): _lib.load().aligner_debug_set_option(b"conv_narrow_ft", int(os.environ["FT"])); print("narrow frame tiles forced to", os.environ["FT"])
 params = aligner_amd.AlignmentEncoderParams.random(512, 80, 80, dev, seed=3)
 text = torch.randn(64, 512, 200, device=dev); mel = torch.randn(64, 80, 900, device=dev)
 def time_us(fn, it=20):
