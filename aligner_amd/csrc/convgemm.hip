@@ -70,6 +70,9 @@ static ConvGemmLayout conv_gemm_layout(int B, int Cin, int Cout, int T, int K) {
     return L;
 }
 
+__device__ __forceinline__ float and_maskf(float v, unsigned m) {            // v or +0.0 without a branch
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m);
+}
 __device__ __forceinline__ void cg_split(float v, __bf16 &hi, __bf16 &lo) {
     hi = (__bf16)v;
     lo = (__bf16)(v - (float)hi);
@@ -214,9 +217,14 @@ __device__ __forceinline__ void cg_store_split(const ConvGemmParams &p, const cg
     for (int a = 0; a < NT; ++a) {
         const int ob = 16 * (otile0 + a) + 4 * q;                            // this lane's 4 channels: ob .. ob+3
         if (ob >= 32 * p.nch2) continue;                                     // (a tile past the consumer's last chunk)
-        float bv[4];
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {                                                        // (uniform) clamped loads, masked: no branch per element
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (p.bias && ob + r < p.Cout) ? p.bias[ob + r] : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const int o = ob + r;
+                bv[r] = and_maskf(p.bias[o < p.Cout ? o : p.Cout - 1], o < p.Cout ? ~0u : 0u);
+            }
+        }
         // image [b][chunk = ob / 32][quarter = (ob % 32) / 8][slot] of 16 bytes; this lane's half at + 8 * ((ob % 8) / 4)
         const size_t row = (((size_t)b * p.nch2 + (ob >> 5)) * 4 + ((ob & 31) >> 3)) * p.S2;
         unsigned char *dst0 = reinterpret_cast<unsigned char *>(p.ys + row) + 8 * ((ob & 7) >> 2);
@@ -229,7 +237,7 @@ __device__ __forceinline__ void cg_store_split(const ConvGemmParams &p, const cg
             for (int r = 0; r < 4; ++r) {
                 float v = acc[a][n][r] + bv[r];
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (f >= p.T || ob + r >= p.Cout) v = 0.f;
+                v = and_maskf(v, (f < p.T && ob + r < p.Cout) ? ~0u : 0u);
                 __bf16 hh, ll;
                 cg_split(v, hh, ll);
                 hv[r] = hh;
@@ -375,98 +383,290 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // barrier per chunk would be all latency; what overlaps staging and arithmetic here is the other workgroup of the CU.
 // The weight fragments stream through a ring of four (chunk, tap) steps in registers, as in the wide kernel.
 constexpr int CN_RING = 4;
-template <int KT, int FT, int NT, bool SPLIT>
-__global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
-    constexpr int LROW = cg_lrow(KT, FT);
-    constexpr int CHSLOT = 8 * LROW;                  // slots per chunk: 2 planes x 4 quarters
-    constexpr int NWL = 2 * NT;                       // weight fragment loads per wave and step
-    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = (int)(blockDim.x >> 6);
-    const int q = lane >> 4, j16 = lane & 15;
-    const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
-    const int f0 = bx * 16 * FT;
-    const int nch = p.nch;
 
-    // ---- stage every chunk: piece = 64 consecutive LDS slots, dealt round-robin to the waves ----
-    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xs + (size_t)b * nch * 4 * p.S);
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
+// the weight ring of one wave: CN_RING (chunk, tap) steps of NT output tiles x 2 planes, loaded straight into registers
+template <int NT>
+struct CnRing {
+    cg_u32x4 W[CN_RING][2 * NT];
+    unsigned wvoff;
+    const unsigned char *wbase;
+    size_t wstep;
+    int nstep, rot;
+    // rot: the workgroup walks the steps from a start of its own (step s of the loop is step (s + rot) % nstep of the
+    // layer: a sum's order, nothing else) -- every workgroup streams the SAME weights, and in step they all ask the same
+    // few L2 channels for the same kilobyte at the same time
+    __device__ __forceinline__ void init(const uint4 *wp, int cpad, int nstep_, int wave, int lane, int rot_ = 0) {
+        wvoff = (unsigned)lane * 16u + (unsigned)(NT * wave * 2) * 1024u;    // this wave's tiles: 2 KB each, in a row
+        wbase = reinterpret_cast<const unsigned char *>(wp);
+        wstep = (size_t)(cpad / 16) * 2 * 1024;                             // bytes per step
+        nstep = nstep_;
+        rot = rot_ % nstep_;
+    }
+    __device__ __forceinline__ int phys(int s) const {                       // loop step -> the layer's step
+        int ps = (s < nstep ? s : nstep - 1) + rot;                          // clamped: the counts stay exact
+        return ps >= nstep ? ps - nstep : ps;
+    }
+    template <int I>
+    __device__ __forceinline__ void load(int s) {
+        const unsigned char *sb = wbase + (size_t)phys(s) * wstep;
+        cg_wload<0>(W[I][0], wvoff, sb);
+        cg_wload<1024>(W[I][1], wvoff, sb);
+        if (NT == 2) {
+            cg_wload<2048>(W[I][2 * NT - 2], wvoff, sb);
+            cg_wload<3072>(W[I][2 * NT - 1], wvoff, sb);
+        }
+    }
+    __device__ __forceinline__ void prime() {                               // steps 0 .. CN_RING-1
+        load<0>(0); load<1>(1); load<2>(2); load<3>(3);
+    }
+    template <int I, int CNT>
+    __device__ __forceinline__ void wait() {                                // ... until at most CNT younger operations are in flight
+        if (NT == 2) cg_wait4<CNT>(W[I][0], W[I][1], W[I][2], W[I][3]);
+        else         cg_wait2<CNT>(W[I][0], W[I][1]);
+    }
+    // The clamped re-loads of the last steps are still in flight INTO the ring's registers when the steps are done: this wait
+    // names every one of them (PEND = operations issued since that may stay in flight), or hipcc -- for whom they are dead
+    // after the last MFMA -- hands them to the next instructions and the landing loads overwrite those (seen: a lane's
+    // channel index in the epilogue, i.e. stores to another wave's channels, one run in a few).
+    template <int PEND>
+    __device__ __forceinline__ void drain() {
+        wait<0, PEND>(); wait<1, PEND>(); wait<2, PEND>(); wait<3, PEND>();
+    }
+};
+static_assert(CN_RING == 4, "CnRing::prime / drain spell the four slots out");
+
+// all steps of one layer for one wave: X fragments from the LDS image at `xl` ([chunk][plane][quarter][LROW] of 16 bytes),
+// W through the (primed) ring; WA: the weights are the MFMA's A operand (output channels on the M axis: split-format
+// epilogues), else the activations are (frames on the M axis: fp32 epilogue)
+template <int KT, int FT, int NT, bool WA, int I>
+__device__ __forceinline__ void cn_step(CnRing<NT> &R, const unsigned char *xl, int s, int lane, cg_f32x4 (&acc)[NT][FT]) {
+    constexpr int LROW = cg_lrow(KT, FT), CHSLOT = 8 * LROW;
+    R.template wait<I, (CN_RING - 1) * 2 * NT>();
+    if (s < R.nstep) {                                                       // (uniform; only the last group is partial)
+        const int ps = R.phys(s);
+        const int c = ps / KT, t = ps - c * KT;
+        const unsigned char *st = xl + (size_t)c * CHSLOT * 16 + (unsigned)((lane >> 4) * LROW + (lane & 15)) * 16u + t * 16;
+        const cg_bf16x8 wh0 = __builtin_bit_cast(cg_bf16x8, R.W[I][0]), wl0 = __builtin_bit_cast(cg_bf16x8, R.W[I][1]);
+        const cg_bf16x8 wh1 = __builtin_bit_cast(cg_bf16x8, R.W[I][2 * NT - 2]), wl1 = __builtin_bit_cast(cg_bf16x8, R.W[I][2 * NT - 1]);
+        // fragments one frame tile ahead of their MFMAs (as in the wide kernel: left alone, hipcc issues a tile's reads and
+        // waits for them at once -- an LDS round trip per 3 * NT MFMAs, with one or two waves per SIMD to hide it)
+        cg_bf16x8 xh = *reinterpret_cast<const cg_bf16x8 *>(st);
+        cg_bf16x8 xlo = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW) * 16);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int n = 0; n < FT; ++n) {
+            cg_bf16x8 nh = xh, nl = xlo;
+            if (n + 1 < FT) {
+                nh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * (n + 1)) * 16);
+                nl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * (n + 1)) * 16);
+            }
+            acc[0][n] = cg_mfma<WA>(xlo, wh0, acc[0][n]);
+            if (NT == 2) acc[NT - 1][n] = cg_mfma<WA>(xlo, wh1, acc[NT - 1][n]);
+            acc[0][n] = cg_mfma<WA>(xh, wl0, acc[0][n]);
+            if (NT == 2) acc[NT - 1][n] = cg_mfma<WA>(xh, wl1, acc[NT - 1][n]);
+            acc[0][n] = cg_mfma<WA>(xh, wh0, acc[0][n]);
+            if (NT == 2) acc[NT - 1][n] = cg_mfma<WA>(xh, wh1, acc[NT - 1][n]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);              // DS read (the next tile's)
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);         // MFMA (this tile's)
+            xh = nh;
+            xlo = nl;
+        }
+    }
+    // the MFMAs above have read the slot before the loads below may overwrite it
+    if (NT == 2) asm volatile("" : "+v"(acc[0][FT - 1]), "+v"(acc[NT - 1][FT - 1]));
+    else         asm volatile("" : "+v"(acc[0][FT - 1]));
+    __builtin_amdgcn_sched_barrier(0);
+    R.template load<I>(s + CN_RING);
+}
+template <int KT, int FT, int NT, bool WA>
+__device__ __forceinline__ void cn_steps(CnRing<NT> &R, const unsigned char *xl, int lane, cg_f32x4 (&acc)[NT][FT]) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int n = 0; n < FT; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < R.nstep; s0 += CN_RING) {
+        cn_step<KT, FT, NT, WA, 0>(R, xl, s0 + 0, lane, acc);
+        cn_step<KT, FT, NT, WA, 1>(R, xl, s0 + 1, lane, acc);
+        cn_step<KT, FT, NT, WA, 2>(R, xl, s0 + 2, lane, acc);
+        cn_step<KT, FT, NT, WA, 3>(R, xl, s0 + 3, lane, acc);
+    }
+}
+
+// stage every chunk of one frame tile into LDS: piece = 64 consecutive slots, dealt round-robin to the waves
+template <int KT, int FT>
+__device__ __forceinline__ void cn_stage_all(const uint4 *xs, unsigned long long xs_plane, int S, int nch, int b, int f0, int wave,
+                                             int nw, int lane, unsigned lds_dst) {
+    constexpr int LROW = cg_lrow(KT, FT), CHSLOT = 8 * LROW;
+    const unsigned char *xbase = reinterpret_cast<const unsigned char *>(xs + (size_t)b * nch * 4 * S);
     const int npiece = nch * CHSLOT / 64;
     for (int pc = wave; pc < npiece; pc += nw) {
         const int i = 64 * pc + lane;
         const int c = i / CHSLOT, r = i - c * CHSLOT;
         const int plane = r / (4 * LROW), qq = (r / LROW) & 3, s = r % LROW;
-        const unsigned voff = (unsigned)(((size_t)plane * p.xs_plane + ((size_t)c * 4 + qq) * p.S + f0 + s) * 16);
-        cg_dma16(lds0 + (unsigned)pc * 1024u, voff, xbase);
+        const unsigned voff = (unsigned)(((size_t)plane * xs_plane + ((size_t)c * 4 + qq) * S + f0 + s) * 16);
+        cg_dma16(lds_dst + (unsigned)pc * 1024u, voff, xbase);
     }
-    // ---- weights: ring of CN_RING steps, step s = chunk * KT + tap, this wave's NT tiles x 2 planes in a row ----
-    const int nstep = nch * KT;
-    const unsigned wvoff = (unsigned)lane * 16u + (unsigned)(NT * wave * 2) * 1024u;
-    const unsigned char *wbase = reinterpret_cast<const unsigned char *>(p.wp);
-    const size_t wstep = (size_t)(p.cpad / 16) * 2 * 1024;
-    cg_u32x4 W[CN_RING][2 * NT];
-    auto load_w = [&](int s, cg_u32x4 (&w)[2 * NT]) {
-        const unsigned char *sb = wbase + (size_t)(s < nstep ? s : nstep - 1) * wstep;   // clamped: the counts stay exact
-        cg_wload<0>(w[0], wvoff, sb);
-        cg_wload<1024>(w[1], wvoff, sb);
-        if (NT == 2) {
-            cg_wload<2048>(w[2 * NT - 2], wvoff, sb);
-            cg_wload<3072>(w[2 * NT - 1], wvoff, sb);
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < CN_RING; ++i) load_w(i, W[i]);
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * NWL) : "memory");   // this wave's staging pieces have landed ...
-    __builtin_amdgcn_s_barrier();                                            // ... and everybody's
+}
 
+template <int KT, int FT, int NT, bool SPLIT>
+__global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
+    const int f0 = bx * 16 * FT;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
+    cn_stage_all<KT, FT>(p.xs, p.xs_plane, p.S, p.nch, b, f0, wave, nw, lane, lds0);
+    CnRing<NT> R;
+    R.init(p.wp, p.cpad, p.nch * KT, wave, lane, (int)blockIdx.x);
+    R.prime();
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * 2 * NT) : "memory");   // this wave's staging pieces have landed ...
+    __builtin_amdgcn_s_barrier();                                               // ... and everybody's
     cg_f32x4 acc[NT][FT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int n = 0; n < FT; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned lbase = (unsigned)(q * LROW + j16) * 16u;
-
-    for (int s0 = 0; s0 < nstep; s0 += CN_RING) {
-#pragma unroll
-        for (int i = 0; i < CN_RING; ++i) {
-            const int s = s0 + i;
-            if (NT == 2) cg_wait4<(CN_RING - 1) * NWL>(W[i][0], W[i][1], W[i][2], W[i][3]);
-            else         cg_wait2<(CN_RING - 1) * NWL>(W[i][0], W[i][1]);
-            if (s < nstep) {                                                 // (uniform; only the last group is partial)
-                const int c = s / KT, t = s - c * KT;
-                const unsigned char *st = cg_smem + (size_t)c * CHSLOT * 16 + lbase + t * 16;
-                const cg_bf16x8 wh0 = __builtin_bit_cast(cg_bf16x8, W[i][0]), wl0 = __builtin_bit_cast(cg_bf16x8, W[i][1]);
-                const cg_bf16x8 wh1 = __builtin_bit_cast(cg_bf16x8, W[i][2 * NT - 2]), wl1 = __builtin_bit_cast(cg_bf16x8, W[i][2 * NT - 1]);
-#pragma unroll
-                for (int n = 0; n < FT; ++n) {
-                    const cg_bf16x8 xh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * n) * 16);
-                    const cg_bf16x8 xl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * n) * 16);
-                    acc[0][n] = cg_mfma<SPLIT>(xl, wh0, acc[0][n]);
-                    acc[0][n] = cg_mfma<SPLIT>(xh, wl0, acc[0][n]);
-                    acc[0][n] = cg_mfma<SPLIT>(xh, wh0, acc[0][n]);
-                    if (NT == 2) {
-                        acc[NT - 1][n] = cg_mfma<SPLIT>(xl, wh1, acc[NT - 1][n]);
-                        acc[NT - 1][n] = cg_mfma<SPLIT>(xh, wl1, acc[NT - 1][n]);
-                        acc[NT - 1][n] = cg_mfma<SPLIT>(xh, wh1, acc[NT - 1][n]);
-                    }
-                }
-            }
-            asm volatile("" : "+v"(acc[0][FT - 1]), "+v"(acc[NT - 1][FT - 1]));
-            __builtin_amdgcn_sched_barrier(0);
-            load_w(s + CN_RING, W[i]);
-        }
-    }
-    // the clamped re-loads of the last steps are still in flight INTO the ring's registers: the wait names every one of
-    // them, or hipcc -- for whom they are dead after the last MFMA -- hands them to the epilogue's first instructions and
-    // the landing loads overwrite those (seen: a lane's channel index, i.e. stores to another wave's channels)
-#pragma unroll
-    for (int i = 0; i < CN_RING; ++i) {
-        if (NT == 2) cg_wait4<0>(W[i][0], W[i][1], W[i][2], W[i][3]);
-        else         cg_wait2<0>(W[i][0], W[i][1]);
-    }
+    cn_steps<KT, FT, NT, SPLIT>(R, cg_smem, lane, acc);
+    R.template drain<0>();
     if (SPLIT) cg_store_split<NT, FT>(p, acc, b, NT * wave, f0, lane);
     else       cg_store_f32<NT, FT>(p, acc, b, NT * wave, f0, lane);
+}
+
+// ---- a run of narrow layers in ONE kernel (the mel encoder: 80 -> 160 k=3, 160 -> 80, 80 -> 80) ----
+// Layers after the first have k = 1, so a frame tile of layer l+1 needs exactly the same frames of layer l: the
+// workgroup keeps its tile on the CU.  Layer l's epilogue writes the split image of layer l+1's input into a second LDS
+// buffer (same [chunk][plane][quarter][slot] layout the global images have: 8-byte ds_writes, a lane's 4 channels of one
+// frame), one barrier, and the same step loop runs again on it with the next layer's weight ring -- primed before the
+// epilogue, so the ring's first loads fly under it.  Nothing between the layers touches HBM: at [64, 80, 900] the three
+// kernels moved 23 + 37 | 37 + 18 | 18 + 18 MB, this one 23 + 18 MB.
+struct FusedLayer { const uint4 *wp; const float *bias; int nch, cpad, Cout, relu; };
+struct ConvFusedParams {
+    const uint4 *xs; unsigned long long xs_plane; int S, nx;
+    FusedLayer L[3];
+    ConvGemmParams out;       // the last layer's epilogue (bias, relu, Cout, T, y)
+    int ldsB;                 // byte offset of the second LDS buffer
+    unsigned long long *stamps;   // debug (nullable): [workgroup][wave][8] shader clock (aligner_debug_set_stamps)
+};
+#define CF_STAMP(k)                                                                                    \
+    do {                                                                                               \
+        if (p.stamps && (threadIdx.x & 63) == 0)                                                       \
+            p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// the accumulators (output channels on the M axis) -> the next layer's LDS image; frames >= T and channels >= Cout are
+// zeros, and so are the tiles of the image's last chunk that no wave owns
+template <int NT, int FT>
+__device__ __forceinline__ void cg_store_lds(unsigned char *dst, int nch_next, const FusedLayer &L, int T, int f0,
+                                             const cg_f32x4 (&acc)[NT][FT], int wave, int nw, int lane) {
+    constexpr int LROWN = cg_lrow(1, FT);
+    const int q = lane >> 4, j16 = lane & 15;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    auto slot_ptr = [&](int ob, int slot, int plane) {
+        return dst + ((size_t)(((ob >> 5) * 8 + plane * 4 + ((ob & 31) >> 3)) * LROWN + slot)) * 16 + 8 * ((ob & 7) >> 2);
+    };
+    // (no branch in here: a wave's tiles always lie inside the next image -- fused_plan checks NT * nw * 16 <= 32 * nch_next --,
+    // the bias comes as one clamped 16-byte load per tile, masks are selects; the first version's per-element branches
+    // and four dependent bias loads per tile made this epilogue 11 k cycles, more than the layer's arithmetic)
+    const bool has_bias = L.bias != nullptr;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        const int ob = 16 * (NT * wave + a) + 4 * q;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) {                                                      // (uniform)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = ob + r;
+                bv[r] = and_maskf(L.bias[o < L.Cout ? o : L.Cout - 1], o < L.Cout ? ~0u : 0u);
+            }
+        }
+        const unsigned keep[4] = {ob + 0 < L.Cout ? ~0u : 0u, ob + 1 < L.Cout ? ~0u : 0u, ob + 2 < L.Cout ? ~0u : 0u,
+                                  ob + 3 < L.Cout ? ~0u : 0u};
+#pragma unroll
+        for (int n = 0; n < FT; ++n) {
+            const int slot = 16 * n + j16;
+            const unsigned fin = f0 + slot < T ? ~0u : 0u;
+            bf16x4 hv, lv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[a][n][r] + bv[r];
+                if (L.relu) v = fmaxf(v, 0.f);
+                v = and_maskf(v, keep[r] & fin);
+                __bf16 hh, ll;
+                cg_split(v, hh, ll);
+                hv[r] = hh;
+                lv[r] = ll;
+            }
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, slot, 0)) = hv;
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, slot, 1)) = lv;
+        }
+    }
+    for (int tz = NT * nw + wave; tz < 2 * nch_next; tz += nw) {            // tiles nobody computed: the image's padding
+        const int ob = 16 * tz + 4 * q;
+        const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+        for (int n = 0; n < FT; ++n) {
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * n + j16, 0)) = z;
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * n + j16, 1)) = z;
+        }
+    }
+}
+
+template <int KT0, int FT, int N0, int N1, int N2>
+__global__ __launch_bounds__(512) void conv_narrow_fused_kernel(ConvFusedParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6);
+    const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
+    const int f0 = bx * 16 * FT, T = p.out.T;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
+    unsigned char *bufA = cg_smem, *bufB = cg_smem + p.ldsB;
+    CF_STAMP(0);
+    cn_stage_all<KT0, FT>(p.xs, p.xs_plane, p.S, p.L[0].nch, b, f0, wave, nw, lane, lds0);
+    CnRing<N0> R0;
+    R0.init(p.L[0].wp, p.L[0].cpad, p.L[0].nch * KT0, wave, lane, (int)blockIdx.x);
+    R0.prime();
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * 2 * N0) : "memory");
+    __builtin_amdgcn_s_barrier();
+    CF_STAMP(1);
+    CnRing<N1> R1;
+    R1.init(p.L[1].wp, p.L[1].cpad, p.L[1].nch, wave, lane, (int)blockIdx.x);
+    {
+        cg_f32x4 acc[N0][FT];
+        cn_steps<KT0, FT, N0, true>(R0, bufA, lane, acc);
+        CF_STAMP(2);
+        R1.prime();                                                          // the next layer's first weights fly under the epilogue
+        R0.template drain<CN_RING * 2 * N1>();
+        cg_store_lds<N0, FT>(bufB, p.L[1].nch, p.L[0], T, f0, acc, wave, nw, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    CF_STAMP(3);
+    if (N2 == 0) {
+        cg_f32x4 acc[N1][FT];
+        cn_steps<1, FT, N1, false>(R1, bufB, lane, acc);
+        R1.template drain<0>();
+        cg_store_f32<N1, FT>(p.out, acc, b, N1 * wave, f0, lane);
+    } else {
+        constexpr int M2 = N2 > 0 ? N2 : 1;
+        CnRing<M2> R2;
+        R2.init(p.L[2].wp, p.L[2].cpad, p.L[2].nch, wave, lane, (int)blockIdx.x);
+        {
+            cg_f32x4 acc[N1][FT];
+            cn_steps<1, FT, N1, true>(R1, bufB, lane, acc);
+            CF_STAMP(4);
+            R2.prime();
+            R1.template drain<CN_RING * 2 * M2>();
+            cg_store_lds<N1, FT>(bufA, p.L[2].nch, p.L[1], T, f0, acc, wave, nw, lane);   // (layer 0's image is dead: everybody passed the barrier)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        CF_STAMP(5);
+        cg_f32x4 acc[M2][FT];
+        cn_steps<1, FT, M2, false>(R2, bufA, lane, acc);
+        R2.template drain<0>();
+        CF_STAMP(6);
+        cg_store_f32<M2, FT>(p.out, acc, b, M2 * wave, f0, lane);
+        CF_STAMP(7);
+    }
 }
 
 template <int KT, int FT, bool SPLIT>
@@ -485,6 +685,15 @@ static int launch_conv_narrow(const ConvGemmParams &p, int nw, hipStream_t s) {
     auto kern = conv_narrow_kernel<KT, FT, NT, SPLIT>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)p.B), dim3(64 * nw), lds, s, p);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
+template <int KT0, int FT, int N0, int N1, int N2>
+static int launch_conv_fused(const ConvFusedParams &p, int nw, int B, size_t lds, hipStream_t s) {
+    auto kern = conv_narrow_fused_kernel<KT0, FT, N0, N1, N2>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)B), dim3(64 * nw), lds, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
@@ -593,6 +802,51 @@ static size_t split_image_bytes(int B, int Cin, int T, int K) {
     return align_up((2 * (size_t)B * nch * 4 * S + 512) * sizeof(uint4), 256);
 }
 
+// A run of narrow layers at the END of a stack as one kernel (conv_narrow_fused_kernel): how many layers (0, 2 or 3),
+// with the launch's numbers.
+struct FusedPlan { int count, FT, nw, N[3], nx; size_t lds, ldsB; };
+static FusedPlan fused_plan(const ConvStackLayer *L, int n, int B, int T) {
+    FusedPlan F{};
+    if (g_opt_conv_no_fuse) return F;
+    for (int cnt : {3, 2}) {
+        if (cnt > n) continue;
+        const ConvStackLayer *G = L + (n - cnt);
+        bool ok = conv_form(G[0].Cin, G[0].Cout, G[0].K) == CG_NARROW;
+        for (int j = 1; j < cnt && ok; ++j) ok = G[j].K == 1 && conv_form(G[j].Cin, G[j].Cout, 1) == CG_NARROW;
+        if (!ok) continue;
+        const int cpad0 = conv_cpad(CG_NARROW, G[0].Cout);
+        F.N[0] = cpad0 > 128 ? 2 : 1;
+        F.nw = cpad0 / (16 * F.N[0]);
+        F.N[2] = 0;
+        for (int j = 1; j < cnt && ok; ++j) {
+            const int tiles = (G[j].Cout + 15) / 16;
+            F.N[j] = (tiles + F.nw - 1) / F.nw;
+            ok = F.N[j] <= 2 && F.N[j] * F.nw * 16 <= conv_cpad(CG_NARROW, G[j].Cout);   // every wave's tiles exist in the prepared image
+            // ... and the producer's tiles lie inside this layer's input image (cg_store_lds has no range check)
+            ok = ok && F.N[j - 1] * F.nw * 16 <= 32 * ((G[j].Cin + CG_CH - 1) / CG_CH);
+        }
+        const int key = F.N[0] * 100 + F.N[1] * 10 + F.N[2];
+        ok = ok && (key == 110 || key == 111 || key == 210 || key == 211 || key == 220);   // the instantiated forms
+        if (!ok) continue;
+        const size_t lds_max = (size_t)device_lds_limit();
+        for (int ft : {8, 4}) {
+            if (g_opt_conv_narrow_ft && ft != g_opt_conv_narrow_ft) continue;           // testing: aligner_debug_set_option
+            const size_t nch0 = (G[0].Cin + CG_CH - 1) / CG_CH, nch1 = (G[1].Cin + CG_CH - 1) / CG_CH;
+            size_t a = nch0 * 8 * cg_lrow(G[0].K, ft) * 16;
+            if (cnt == 3) {
+                const size_t a2 = (size_t)((G[2].Cin + CG_CH - 1) / CG_CH) * 8 * cg_lrow(1, ft) * 16;
+                a = a2 > a ? a2 : a;
+            }
+            const size_t bsz = nch1 * 8 * cg_lrow(1, ft) * 16;
+            if (a + bsz > lds_max) continue;
+            F.count = cnt; F.FT = ft; F.ldsB = a; F.lds = a + bsz;
+            F.nx = (T + 16 * ft - 1) / (16 * ft);
+            return F;
+        }
+    }
+    return FusedPlan{};
+}
+
 size_t conv_stack_workspace_bytes(const ConvStackLayer *L, int n, int B, int T) {
     size_t img = 0, tmp = 0;
     for (int i = 0; i < n; ++i) {
@@ -633,7 +887,30 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
     int cur = 0;
     int rc = split_pass(x, bufs[0], L[0].Cin, L[0].K);
     if (rc != ALIGNER_OK) return rc;
+    const FusedPlan F = fused_plan(L, n, B, T);
     for (int i = 0; i < n; ++i) {
+        if (F.count && i == n - F.count) {                                   // the stack's last layers: one kernel, tiles kept on the CU
+            const ConvStackLayer *G = L + i;
+            ConvFusedParams fp{};
+            const int nch0 = (G[0].Cin + CG_CH - 1) / CG_CH, S0 = (T + 2 * (G[0].K / 2) + 15) / 16 * 16;
+            fp.stamps = g_debug_stamps;
+            fp.xs = bufs[cur]; fp.xs_plane = (unsigned long long)B * nch0 * 4 * S0; fp.S = S0; fp.nx = F.nx; fp.ldsB = (int)F.ldsB;
+            for (int j = 0; j < F.count; ++j)
+                fp.L[j] = FusedLayer{static_cast<const uint4 *>(G[j].prepared), G[j].bias, (G[j].Cin + CG_CH - 1) / CG_CH,
+                                     conv_cpad(CG_NARROW, G[j].Cout), G[j].Cout, G[j].relu};
+            const ConvStackLayer &Z = G[F.count - 1];
+            fp.out.bias = Z.bias; fp.out.y = y; fp.out.B = B; fp.out.Cout = Z.Cout; fp.out.T = T; fp.out.relu = Z.relu;
+            const int key = F.N[0] * 100 + F.N[1] * 10 + F.N[2], K0 = G[0].K;
+#define CF(KT0, FTV, A, Bn, C) launch_conv_fused<KT0, FTV, A, Bn, C>(fp, F.nw, B, F.lds, s)
+#define CF_FT(KT0, A, Bn, C) (F.FT == 8 ? CF(KT0, 8, A, Bn, C) : CF(KT0, 4, A, Bn, C))
+#define CF_K(A, Bn, C) (K0 == 1 ? CF_FT(1, A, Bn, C) : K0 == 3 ? CF_FT(3, A, Bn, C) : CF_FT(5, A, Bn, C))
+            rc = key == 110 ? CF_K(1, 1, 0) : key == 111 ? CF_K(1, 1, 1) : key == 210 ? CF_K(2, 1, 0) : key == 211 ? CF_K(2, 1, 1)
+                                                                                                       : CF_K(2, 2, 0);
+#undef CF
+#undef CF_FT
+#undef CF_K
+            return rc;
+        }
         const ConvPlan P = conv_plan(B, L[i].Cin, L[i].Cout, T, L[i].K);
         const int nch = (L[i].Cin + CG_CH - 1) / CG_CH, S = (T + 2 * (L[i].K / 2) + 15) / 16 * 16;
         const bool last = i + 1 == n;

@@ -245,6 +245,41 @@ def test_wide_conv_gemm_form(dev, B, Ci, Co, T, K, relu):
     assert (got.cpu() - S.conv1d(x, w, None, relu)).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("B,T,chans,ks", [
+    (3, 333, (80, 160, 80, 80), (3, 1, 1)),        # the mel encoder: waves own (2, 1, 1) output tiles in the three layers
+    (2, 200, (48, 80, 80), (5, 1)),                # (1, 1): six waves, the image's last chunk half padding
+    (2, 130, (96, 80, 80, 80), (1, 1, 1)),         # (1, 1, 1)
+    (2, 90, (64, 160, 160), (3, 1)),               # (2, 2)
+    (5, 100, (64, 160, 80), (1, 1)),               # (2, 1)
+    (64, 900, (80, 160, 80, 80), (3, 1, 1)),       # BASELINE configs[2]'s mel encoder at its full size
+])
+def test_trailing_narrow_layers_in_one_kernel(dev, B, T, chans, ks):
+    """conv_narrow_fused_kernel: a stack's trailing narrow layers (k = 1 after the first) with the tiles kept in LDS between
+    the layers -- against the fp32 oracle stack at 1e-4 and against the same stack as separate kernels (debug option)."""
+    from aligner_amd import _lib
+    from aligner_amd.softattn import encode
+    from oracle import softattn_oracle as S
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + T)
+    x = torch.randn(B, chans[0], T, generator=g)
+    stack = [(torch.randn(co, ci, k, generator=g) / (ci * k) ** 0.5, torch.randn(co, generator=g) * 0.1)
+             for ci, co, k in zip(chans[:-1], chans[1:], ks)]
+    dstack = [(w.to(dev), b.to(dev)) for w, b in stack]
+    xd = x.to(dev)
+    for rep in range(2):
+        got = encode(xd, dstack)
+    try:
+        assert lib.aligner_debug_set_option(b"conv_no_fuse", 1) == 0
+        sep = encode(xd, dstack)
+    finally:
+        lib.aligner_debug_set_option(b"conv_no_fuse", 0)
+    torch.cuda.synchronize()
+    assert (got - sep).abs().max().item() < 5e-5
+    if B * T <= 4000:                                       # (the full-size case is checked against the separate kernels only)
+        want = S.encode(x, stack)
+        assert (got.cpu() - want).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("ft", [8, 4, 2])
 def test_narrow_conv_every_frame_tile(dev, ft):
     """conv_narrow_kernel's three tile sizes (the launch picks one from the batch size: small test batches would only

@@ -23,7 +23,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 KERNELS = ["softattn_kernel", "maxpath_pipelined_kernel", "expand_kernel", "conv_gemm_kernel", "conv1d_prepared_kernel",
-           "conv_split_kernel", "mel_encoder_kernel", "mobo_chain_map_kernel"]
+           "conv_split_kernel", "conv_narrow_fused_kernel", "conv_narrow_kernel", "mobo_chain_map_kernel"]
 
 
 def collect(dirs):
