@@ -37,6 +37,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "aligner_amd.h"
 #include "common.h"
@@ -382,21 +383,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
 // [chunk][plane][quarter][slot]): these layers have 3 to 32 chunks of a few hundred MFMA cycles each -- a ring with a
 // barrier per chunk would be all latency; what overlaps staging and arithmetic here is the other workgroup of the CU.
 // The weight fragments stream through a ring of four (chunk, tap) steps in registers, as in the wide kernel.
-constexpr int CN_RING = 4;
+constexpr int CN_RING = 4;           // weight-ring depth of the one-layer kernel; the fused kernel picks per layer (4 or 8)
 
-// the weight ring of one wave: CN_RING (chunk, tap) steps of NT output tiles x 2 planes, loaded straight into registers
-template <int NT>
+template <int I, int N, class F>
+__device__ __forceinline__ void cg_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cg_static_for<I + 1, N>(f);
+    }
+}
+
+// the weight ring of one wave: RD (chunk, tap) steps of NT output tiles x 2 planes, loaded straight into registers
+template <int NT, int RD = CN_RING>
 struct CnRing {
-    cg_u32x4 W[CN_RING][2 * NT];
+    cg_u32x4 W[RD][2 * NT];
     unsigned wvoff;
     const unsigned char *wbase;
     size_t wstep;
     int nstep, rot;
-    // rot: the workgroup walks the steps from a start of its own (step s of the loop is step (s + rot) % nstep of the
-    // layer: a sum's order, nothing else) -- every workgroup streams the SAME weights, and in step they all ask the same
-    // few L2 channels for the same kilobyte at the same time
-    __device__ __forceinline__ void init(const uint4 *wp, int cpad, int nstep_, int wave, int lane, int rot_ = 0) {
-        wvoff = (unsigned)lane * 16u + (unsigned)(NT * wave * 2) * 1024u;    // this wave's tiles: 2 KB each, in a row
+    // wt: which pair / tile of output channels this wave owns.  rot: the workgroup walks the steps from a start of its own
+    // (step s of the loop is step (s + rot) % nstep of the layer: a sum's order, nothing else)
+    __device__ __forceinline__ void init(const uint4 *wp, int cpad, int nstep_, int wt, int lane, int rot_ = 0) {
+        wvoff = (unsigned)lane * 16u + (unsigned)(NT * wt * 2) * 1024u;      // this wave's tiles: 2 KB each, in a row
         wbase = reinterpret_cast<const unsigned char *>(wp);
         wstep = (size_t)(cpad / 16) * 2 * 1024;                             // bytes per step
         nstep = nstep_;
@@ -416,8 +424,8 @@ struct CnRing {
             cg_wload<3072>(W[I][2 * NT - 1], wvoff, sb);
         }
     }
-    __device__ __forceinline__ void prime() {                               // steps 0 .. CN_RING-1
-        load<0>(0); load<1>(1); load<2>(2); load<3>(3);
+    __device__ __forceinline__ void prime() {                               // steps 0 .. RD-1
+        cg_static_for<0, RD>([&](auto ic) { load<decltype(ic)::value>(decltype(ic)::value); });
     }
     template <int I, int CNT>
     __device__ __forceinline__ void wait() {                                // ... until at most CNT younger operations are in flight
@@ -430,18 +438,18 @@ struct CnRing {
     // channel index in the epilogue, i.e. stores to another wave's channels, one run in a few).
     template <int PEND>
     __device__ __forceinline__ void drain() {
-        wait<0, PEND>(); wait<1, PEND>(); wait<2, PEND>(); wait<3, PEND>();
+        cg_static_for<0, RD>([&](auto ic) { wait<decltype(ic)::value, PEND>(); });
     }
 };
-static_assert(CN_RING == 4, "CnRing::prime / drain spell the four slots out");
 
-// all steps of one layer for one wave: X fragments from the LDS image at `xl` ([chunk][plane][quarter][LROW] of 16 bytes),
-// W through the (primed) ring; WA: the weights are the MFMA's A operand (output channels on the M axis: split-format
-// epilogues), else the activations are (frames on the M axis: fp32 epilogue)
-template <int KT, int FT, int NT, bool WA, int I>
-__device__ __forceinline__ void cn_step(CnRing<NT> &R, const unsigned char *xl, int s, int lane, cg_f32x4 (&acc)[NT][FT]) {
-    constexpr int LROW = cg_lrow(KT, FT), CHSLOT = 8 * LROW;
-    R.template wait<I, (CN_RING - 1) * 2 * NT>();
+// one step of one layer for one wave: X fragments from the LDS image at `xl` ([chunk][plane][quarter][LROW] of 16 bytes;
+// the caller has added the wave's first frame tile), W from slot I of the (primed) ring; FTW frame tiles.  WA: the
+// weights are the MFMA's A operand (output channels on the M axis: split-format epilogues), else the activations are
+// (frames on the M axis: fp32 epilogue)
+template <int KT, int LROW, int FTW, int NT, int RD, bool WA, int I>
+__device__ __forceinline__ void cn_step(CnRing<NT, RD> &R, const unsigned char *xl, int s, int lane, cg_f32x4 (&acc)[NT][FTW]) {
+    constexpr int CHSLOT = 8 * LROW;
+    R.template wait<I, (RD - 1) * 2 * NT>();
     if (s < R.nstep) {                                                       // (uniform; only the last group is partial)
         const int ps = R.phys(s);
         const int c = ps / KT, t = ps - c * KT;
@@ -454,9 +462,9 @@ __device__ __forceinline__ void cn_step(CnRing<NT> &R, const unsigned char *xl, 
         cg_bf16x8 xlo = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW) * 16);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-        for (int n = 0; n < FT; ++n) {
+        for (int n = 0; n < FTW; ++n) {
             cg_bf16x8 nh = xh, nl = xlo;
-            if (n + 1 < FT) {
+            if (n + 1 < FTW) {
                 nh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * (n + 1)) * 16);
                 nl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * (n + 1)) * 16);
             }
@@ -473,23 +481,22 @@ __device__ __forceinline__ void cn_step(CnRing<NT> &R, const unsigned char *xl, 
         }
     }
     // the MFMAs above have read the slot before the loads below may overwrite it
-    if (NT == 2) asm volatile("" : "+v"(acc[0][FT - 1]), "+v"(acc[NT - 1][FT - 1]));
-    else         asm volatile("" : "+v"(acc[0][FT - 1]));
+    if (NT == 2) asm volatile("" : "+v"(acc[0][FTW - 1]), "+v"(acc[NT - 1][FTW - 1]));
+    else         asm volatile("" : "+v"(acc[0][FTW - 1]));
     __builtin_amdgcn_sched_barrier(0);
-    R.template load<I>(s + CN_RING);
+    R.template load<I>(s + RD);
 }
-template <int KT, int FT, int NT, bool WA>
-__device__ __forceinline__ void cn_steps(CnRing<NT> &R, const unsigned char *xl, int lane, cg_f32x4 (&acc)[NT][FT]) {
+template <int KT, int LROW, int FTW, int NT, int RD, bool WA>
+__device__ __forceinline__ void cn_steps(CnRing<NT, RD> &R, const unsigned char *xl, int lane, cg_f32x4 (&acc)[NT][FTW]) {
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int n = 0; n < FT; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < R.nstep; s0 += CN_RING) {
-        cn_step<KT, FT, NT, WA, 0>(R, xl, s0 + 0, lane, acc);
-        cn_step<KT, FT, NT, WA, 1>(R, xl, s0 + 1, lane, acc);
-        cn_step<KT, FT, NT, WA, 2>(R, xl, s0 + 2, lane, acc);
-        cn_step<KT, FT, NT, WA, 3>(R, xl, s0 + 3, lane, acc);
-    }
+        for (int n = 0; n < FTW; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < R.nstep; s0 += RD)
+        cg_static_for<0, RD>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            cn_step<KT, LROW, FTW, NT, RD, WA, I>(R, xl, s0 + I, lane, acc);
+        });
 }
 
 // stage every chunk of one frame tile into LDS: piece = 64 consecutive slots, dealt round-robin to the waves
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * 2 * NT) : "memory");   // this wave's staging pieces have landed ...
     __builtin_amdgcn_s_barrier();                                               // ... and everybody's
     cg_f32x4 acc[NT][FT];
-    cn_steps<KT, FT, NT, SPLIT>(R, cg_smem, lane, acc);
+    cn_steps<KT, cg_lrow(KT, FT), FT, NT, CN_RING, SPLIT>(R, cg_smem, lane, acc);
     R.template drain<0>();
     if (SPLIT) cg_store_split<NT, FT>(p, acc, b, NT * wave, f0, lane);
     else       cg_store_f32<NT, FT>(p, acc, b, NT * wave, f0, lane);
@@ -537,6 +544,13 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
 // frame), one barrier, and the same step loop runs again on it with the next layer's weight ring -- primed before the
 // epilogue, so the ring's first loads fly under it.  Nothing between the layers touches HBM: at [64, 80, 900] the three
 // kernels moved 23 + 37 | 37 + 18 | 18 + 18 MB, this one 23 + 18 MB.
+// Waves: 2 * nwt.  Wave (wt, fh) owns output tiles N * wt .. of every layer and frame tiles fh * FT/2 .. (fh+1) * FT/2 - 1:
+// the first version had one wave per channel group and all FT frame tiles -- five waves for the mel encoder, i.e. one SIMD
+// with two of them while three ran one (layer 0: 11.7 k cycles alone, 17.7 k paired; the workgroup waits for the pair).
+// With ten waves (3, 3, 2, 2 per SIMD) every layer's arithmetic and every epilogue is spread over all of them.
+// Ring depth: layer 0 four steps; the k = 1 layers' steps are 12 or 24 MFMAs (200-400 cycles) -- shorter than the
+// weights' trip from L2 --, so their rings hold eight steps: with nch <= 8 that is ALL of the layer's weights, in flight
+// from the moment the previous layer's steps end.
 struct FusedLayer { const uint4 *wp; const float *bias; int nch, cpad, Cout, relu; };
 struct ConvFusedParams {
     const uint4 *xs; unsigned long long xs_plane; int S, nx;
@@ -548,27 +562,27 @@ struct ConvFusedParams {
 #define CF_STAMP(k)                                                                                    \
     do {                                                                                               \
         if (p.stamps && (threadIdx.x & 63) == 0)                                                       \
-            p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+            p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-// the accumulators (output channels on the M axis) -> the next layer's LDS image; frames >= T and channels >= Cout are
-// zeros, and so are the tiles of the image's last chunk that no wave owns
-template <int NT, int FT>
-__device__ __forceinline__ void cg_store_lds(unsigned char *dst, int nch_next, const FusedLayer &L, int T, int f0,
-                                             const cg_f32x4 (&acc)[NT][FT], int wave, int nw, int lane) {
-    constexpr int LROWN = cg_lrow(1, FT);
+// the accumulators (output channels on the M axis) of wave (wt, frame tiles n0 .. n0+FTW-1) -> the next layer's LDS image
+// (rows of LROWN slots); frames >= T and channels >= Cout are zeros, and so are the tiles of the image's last chunk that
+// no wave owns
+template <int NT, int FTW, int LROWN>
+__device__ __forceinline__ void cg_store_lds(unsigned char *dst, int nch_next, const FusedLayer &L, int T, int f0, int n0,
+                                             const cg_f32x4 (&acc)[NT][FTW], int wt, int nwt, int lane) {
     const int q = lane >> 4, j16 = lane & 15;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     auto slot_ptr = [&](int ob, int slot, int plane) {
         return dst + ((size_t)(((ob >> 5) * 8 + plane * 4 + ((ob & 31) >> 3)) * LROWN + slot)) * 16 + 8 * ((ob & 7) >> 2);
     };
-    // (no branch in here: a wave's tiles always lie inside the next image -- fused_plan checks NT * nw * 16 <= 32 * nch_next --,
-    // the bias comes as one clamped 16-byte load per tile, masks are selects; the first version's per-element branches
-    // and four dependent bias loads per tile made this epilogue 11 k cycles, more than the layer's arithmetic)
+    // (no branch in here: a wave's tiles always lie inside the next image -- fused_plan checks NT * nwt * 16 <= 32 * nch_next --,
+    // the bias comes as clamped loads, masks are selects; the first version's per-element branches and four dependent bias
+    // loads per tile made this epilogue 11 k cycles, more than the layer's arithmetic)
     const bool has_bias = L.bias != nullptr;
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-        const int ob = 16 * (NT * wave + a) + 4 * q;
+        const int ob = 16 * (NT * wt + a) + 4 * q;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (has_bias) {                                                      // (uniform)
 #pragma unroll
@@ -580,8 +594,8 @@ __device__ __forceinline__ void cg_store_lds(unsigned char *dst, int nch_next, c
         const unsigned keep[4] = {ob + 0 < L.Cout ? ~0u : 0u, ob + 1 < L.Cout ? ~0u : 0u, ob + 2 < L.Cout ? ~0u : 0u,
                                   ob + 3 < L.Cout ? ~0u : 0u};
 #pragma unroll
-        for (int n = 0; n < FT; ++n) {
-            const int slot = 16 * n + j16;
+        for (int n = 0; n < FTW; ++n) {
+            const int slot = 16 * (n0 + n) + j16;
             const unsigned fin = f0 + slot < T ? ~0u : 0u;
             bf16x4 hv, lv;
 #pragma unroll
@@ -598,73 +612,81 @@ __device__ __forceinline__ void cg_store_lds(unsigned char *dst, int nch_next, c
             *reinterpret_cast<bf16x4 *>(slot_ptr(ob, slot, 1)) = lv;
         }
     }
-    for (int tz = NT * nw + wave; tz < 2 * nch_next; tz += nw) {            // tiles nobody computed: the image's padding
+    for (int tz = NT * nwt + wt; tz < 2 * nch_next; tz += nwt) {            // tiles nobody computed: the image's padding
         const int ob = 16 * tz + 4 * q;
         const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 #pragma unroll
-        for (int n = 0; n < FT; ++n) {
-            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * n + j16, 0)) = z;
-            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * n + j16, 1)) = z;
+        for (int n = 0; n < FTW; ++n) {
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * (n0 + n) + j16, 0)) = z;
+            *reinterpret_cast<bf16x4 *>(slot_ptr(ob, 16 * (n0 + n) + j16, 1)) = z;
         }
     }
 }
 
 template <int KT0, int FT, int N0, int N1, int N2>
-__global__ __launch_bounds__(512) void conv_narrow_fused_kernel(ConvFusedParams p) {
+__global__ __launch_bounds__(768) void conv_narrow_fused_kernel(ConvFusedParams p) {   // <= 12 waves: 168 VGPRs (16 waves: 128, and the rings spill)
+    constexpr int FTW = FT / 2;                          // frame tiles per wave
+    constexpr int LROW0 = cg_lrow(KT0, FT), LROW1 = cg_lrow(1, FT);
+    constexpr int RDA = N1 == 2 ? 4 : 8, RDB = N2 == 2 ? 4 : 8;   // ring depths of the k = 1 layers (32 registers either way)
     extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = (int)(blockDim.x >> 6);
+    const int nw = (int)(blockDim.x >> 6), nwt = nw >> 1;
+    const int wt = wave < nwt ? wave : wave - nwt, fh = wave < nwt ? 0 : 1;
+    const int n0 = fh * FTW;
     const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
     const int f0 = bx * 16 * FT, T = p.out.T;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
     unsigned char *bufA = cg_smem, *bufB = cg_smem + p.ldsB;
+    const unsigned xoff = (unsigned)n0 * 256u;           // this wave's first frame tile inside an image row
     CF_STAMP(0);
     cn_stage_all<KT0, FT>(p.xs, p.xs_plane, p.S, p.L[0].nch, b, f0, wave, nw, lane, lds0);
-    CnRing<N0> R0;
-    R0.init(p.L[0].wp, p.L[0].cpad, p.L[0].nch * KT0, wave, lane, (int)blockIdx.x);
+    CnRing<N0, CN_RING> R0;
+    R0.init(p.L[0].wp, p.L[0].cpad, p.L[0].nch * KT0, wt, lane, (int)blockIdx.x);
     R0.prime();
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CN_RING * 2 * N0) : "memory");
     __builtin_amdgcn_s_barrier();
     CF_STAMP(1);
-    CnRing<N1> R1;
-    R1.init(p.L[1].wp, p.L[1].cpad, p.L[1].nch, wave, lane, (int)blockIdx.x);
+    CnRing<N1, RDA> R1;
+    R1.init(p.L[1].wp, p.L[1].cpad, p.L[1].nch, wt, lane, (int)blockIdx.x);
     {
-        cg_f32x4 acc[N0][FT];
-        cn_steps<KT0, FT, N0, true>(R0, bufA, lane, acc);
+        cg_f32x4 acc[N0][FTW];
+        cn_steps<KT0, LROW0, FTW, N0, CN_RING, true>(R0, bufA + xoff, lane, acc);
         CF_STAMP(2);
-        R1.prime();                                                          // the next layer's first weights fly under the epilogue
-        R0.template drain<CN_RING * 2 * N1>();
-        cg_store_lds<N0, FT>(bufB, p.L[1].nch, p.L[0], T, f0, acc, wave, nw, lane);
+        R1.prime();                                                          // the next layer's weights fly under the epilogue
+        R0.template drain<RDA * 2 * N1>();
+        cg_store_lds<N0, FTW, LROW1>(bufB, p.L[1].nch, p.L[0], T, f0, n0, acc, wt, nwt, lane);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     CF_STAMP(3);
     if (N2 == 0) {
-        cg_f32x4 acc[N1][FT];
-        cn_steps<1, FT, N1, false>(R1, bufB, lane, acc);
+        cg_f32x4 acc[N1][FTW];
+        cn_steps<1, LROW1, FTW, N1, RDA, false>(R1, bufB + xoff, lane, acc);
         R1.template drain<0>();
-        cg_store_f32<N1, FT>(p.out, acc, b, N1 * wave, f0, lane);
+        CF_STAMP(6);
+        cg_store_f32<N1, FTW>(p.out, acc, b, N1 * wt, f0 + 16 * n0, lane);
+        CF_STAMP(7);
     } else {
         constexpr int M2 = N2 > 0 ? N2 : 1;
-        CnRing<M2> R2;
-        R2.init(p.L[2].wp, p.L[2].cpad, p.L[2].nch, wave, lane, (int)blockIdx.x);
+        CnRing<M2, RDB> R2;
+        R2.init(p.L[2].wp, p.L[2].cpad, p.L[2].nch, wt, lane, (int)blockIdx.x);
         {
-            cg_f32x4 acc[N1][FT];
-            cn_steps<1, FT, N1, true>(R1, bufB, lane, acc);
+            cg_f32x4 acc[N1][FTW];
+            cn_steps<1, LROW1, FTW, N1, RDA, true>(R1, bufB + xoff, lane, acc);
             CF_STAMP(4);
             R2.prime();
-            R1.template drain<CN_RING * 2 * M2>();
-            cg_store_lds<N1, FT>(bufA, p.L[2].nch, p.L[1], T, f0, acc, wave, nw, lane);   // (layer 0's image is dead: everybody passed the barrier)
+            R1.template drain<RDB * 2 * M2>();
+            cg_store_lds<N1, FTW, LROW1>(bufA, p.L[2].nch, p.L[1], T, f0, n0, acc, wt, nwt, lane);   // (layer 0's image is dead: everybody passed the barrier)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         CF_STAMP(5);
-        cg_f32x4 acc[M2][FT];
-        cn_steps<1, FT, M2, false>(R2, bufA, lane, acc);
+        cg_f32x4 acc[M2][FTW];
+        cn_steps<1, LROW1, FTW, M2, RDB, false>(R2, bufA + xoff, lane, acc);
         R2.template drain<0>();
         CF_STAMP(6);
-        cg_store_f32<M2, FT>(p.out, acc, b, M2 * wave, f0, lane);
+        cg_store_f32<M2, FTW>(p.out, acc, b, M2 * wt, f0 + 16 * n0, lane);
         CF_STAMP(7);
     }
 }
@@ -688,12 +710,11 @@ static int launch_conv_narrow(const ConvGemmParams &p, int nw, hipStream_t s) {
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
-
 template <int KT0, int FT, int N0, int N1, int N2>
 static int launch_conv_fused(const ConvFusedParams &p, int nw, int B, size_t lds, hipStream_t s) {
     auto kern = conv_narrow_fused_kernel<KT0, FT, N0, N1, N2>;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)B), dim3(64 * nw), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)B), dim3(64 * 2 * nw), lds, s, p);   // two frame halves
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
@@ -818,6 +839,7 @@ static FusedPlan fused_plan(const ConvStackLayer *L, int n, int B, int T) {
         F.N[0] = cpad0 > 128 ? 2 : 1;
         F.nw = cpad0 / (16 * F.N[0]);
         F.N[2] = 0;
+        if (F.nw > 6) continue;                                               // two wave groups of at most six waves (register budget)
         for (int j = 1; j < cnt && ok; ++j) {
             const int tiles = (G[j].Cout + 15) / 16;
             F.N[j] = (tiles + F.nw - 1) / F.nw;

@@ -11,7 +11,7 @@ params = aligner_amd.AlignmentEncoderParams.random(512, 80, 80, dev, seed=3)
 mel = torch.randn(64, 80, 900, device=dev)
 for _ in range(3): encode(mel, params.query_proj)
 torch.cuda.synchronize()
-st = torch.zeros((4096, 8, 8), dtype=torch.int64, device=dev)
+st = torch.zeros((4096, 16, 8), dtype=torch.int64, device=dev)
 lib.aligner_debug_set_stamps(st.data_ptr())
 encode(mel, params.query_proj); torch.cuda.synchronize()
 lib.aligner_debug_set_stamps(None)
@@ -20,7 +20,7 @@ s = s[s[:, 0, 0] > 0]
 names = ["entry", "staged + barrier", "layer 0 steps", "epilogue 0 -> LDS + barrier", "layer 1 steps", "epilogue 1 -> LDS + barrier", "layer 2 steps", "stores issued"]
 print("workgroups stamped:", s.shape[0])
 t0 = np.where(s[:, :, 0] > 0, s[:, :, 0], np.inf).min(axis=1)
-for w in range(8):
+for w in range(16):
     if not (s[:, w, 0] > 0).any(): continue
     row = []
     for k in range(1, 8):
