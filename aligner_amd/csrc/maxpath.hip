@@ -86,6 +86,8 @@ struct MaxpathParams {
     int lds_total;          // bytes of LDS the launch asked for (store_outputs: is there room for its scratch?)
     unsigned    *xring;     // two workgroups per utterance: [B][NT][32] boundary row between the halves (workspace, 0xFF-filled)
     int         *xflag;     // ... [B] first half done (1; 2 = it met a non-finite score), 0xFFFFFFFF until then
+    unsigned    *xwalk;     // ... [B] the backtrack's hand-over from the second half to the first (0xFFFFFFFF until then)
+    int          split_walk;    // ... each half walks its own rows out of its own LDS (its decision words all fit there)
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable; [2B] when utterances are split)
     float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
     void        *path1;     // ALIGNER_F_PATH_PREZEROED: the caller's all-zero dense path; the kernel writes its ones (nullable)
@@ -184,8 +186,12 @@ __device__ __forceinline__ bool tile_in_band(int t, int r0, int nrows, int tx, i
 // room for the bit string -- a very long mel axis on a small workgroup -- each frame bisects the starts.)
 __device__ __forceinline__ int starts_words_of(int Tx) { return ((Tx + 1 + 63) / 64) * 64 + 64; }
 
+// Row / frame ranges (the two-workgroup form, each half storing what it walked): rows [x_lo, x_hi) of `starts` and
+// `dur` (x_hi < 0: through the padding, Tx + 1 / Tx), frames [y_lo, y_hi) of `tok` and the path (y_hi < 0: Ty); startsL
+// must hold rows x_lo .. x_hi (the first row after the range bounds its last token).
 __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int tx, int ty, int *startsL,
-                                              bool distinct_starts = true) {
+                                              bool distinct_starts = true, int x_lo = 0, int x_hi = -1, int y_lo = 0,
+                                              int y_hi = -1) {
     const int tid = threadIdx.x, nthreads = blockDim.x;
     if (p.path1 && p.zero_blocks > 0) {
         // The zeros of the dense path come from the launch's zero workgroups: all of them must have reported before a 1 is
@@ -209,9 +215,11 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
             ty = 0;
         }
     }
-    for (int x = tid; x <= p.Tx; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
+    const int xs_hi = x_hi < 0 ? p.Tx + 1 : x_hi, xd_hi = x_hi < 0 ? p.Tx : x_hi;
+    const int ye = y_hi < 0 ? p.Ty : y_hi;
+    for (int x = x_lo + tid; x < xs_hi; x += nthreads) p.starts[(size_t)b * (p.Tx + 1) + x] = startsL[x];
     if (p.dur)
-        for (int x = tid; x < p.Tx; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
+        for (int x = x_lo + tid; x < xd_hi; x += nthreads) p.dur[(size_t)b * p.Tx + x] = startsL[x + 1] - startsL[x];
     if (!p.tok && !p.path1) return;
     // core.pyx:33 `path[index, y] = 1` on a path the caller zeroed (np.zeros, __init__.py:15): one element per frame
     auto mark_path = [&](int t, int y) {
@@ -228,10 +236,11 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
     int *before = reinterpret_cast<int *>(mark + nmw);    // set bits in the words before word j
     // (the t_x > t_y compatibility result has rows that own no frame: equal starts, so it takes the search)
     const bool room = distinct_starts && (size_t)(starts_words_of(p.Tx) + 2 * nmw) * 4 <= (size_t)p.lds_total;
+    const int xt_hi = (x_hi < 0 || x_hi > tx) ? tx : x_hi;  // tokens x_lo .. xt_hi-1 own the frames of the range
     if (room) {
         for (int j = tid; j < nmw; j += nthreads) mark[j] = 0u;
         __syncthreads();
-        for (int x = 1 + tid; x < tx; x += nthreads) {
+        for (int x = x_lo + 1 + tid; x < xt_hi; x += nthreads) {
             const int st = startsL[x];                      // strictly increasing in x: every bit is set once
             atomicOr(&mark[st >> 5], 1u << (st & 31));
         }
@@ -250,17 +259,17 @@ __device__ __forceinline__ void store_outputs(const MaxpathParams &p, int b, int
             for (int j = j0; j < j0 + per && j < nmw; ++j) { before[j] = run; run += __builtin_popcount(mark[j]); }
         }
         __syncthreads();
-        for (int y = tid; y < p.Ty; y += nthreads) {
+        for (int y = y_lo + tid; y < ye; y += nthreads) {
             int t = -1;
-            if (y < ty) t = before[y >> 5] + __builtin_popcount(mark[y >> 5] & ((2u << (y & 31)) - 1u));
+            if (y < ty) t = x_lo + before[y >> 5] + __builtin_popcount(mark[y >> 5] & ((2u << (y & 31)) - 1u));
             if (p.tok) p.tok[(size_t)b * p.Ty + y] = t;
             if (p.path1 && t >= 0) mark_path(t, y);
         }
     } else {
-        for (int y = tid; y < p.Ty; y += nthreads) {
+        for (int y = y_lo + tid; y < ye; y += nthreads) {
             int t = -1;
             if (y < ty) {
-                int lo = 0, hi = tx - 1;                  // last x with starts[x] <= y
+                int lo = x_lo, hi = xt_hi - 1;            // last x with starts[x] <= y
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     if (startsL[mid] <= y) lo = mid; else hi = mid - 1;
@@ -420,10 +429,12 @@ __device__ __forceinline__ void walk_rows_slow(const unsigned *wrow, int xhi, in
 // 0 -- the fast steps run over it and its outcome is ignored), or the row to resume at in an earlier window (stop).
 template <bool WINDOW>
 __device__ __forceinline__ void walk_chunk(const unsigned *wrow, int c, int &x, int &e, int &startv, int lane, int jb,
-                                           int ntw, int &stop, int *status) {
+                                           int ntw, int &stop, int *status, int klo0 = 1) {
     typedef __attribute__((address_space(3))) const unsigned lds_cu32;
     const unsigned lds_addr = (unsigned)(unsigned long long)(lds_cu32 *)(wrow + 64 * c);
-    const int klo = (c == 0) ? 1 : 0;
+    // klo0 = 1: row 0 of these words is the utterance's row 0 (it starts at frame 0: not walked); 0: it is an ordinary row
+    // (the second workgroup's first row) and leaves e = the last frame of the row before it
+    const int klo = (c == 0) ? klo0 : 0;
     const int off = WINDOW ? (jb << 5) : 0;
     int kent = x - 64 * c;
     while (kent >= klo) {
@@ -458,7 +469,7 @@ __device__ __forceinline__ void walk_chunk(const unsigned *wrow, int c, int &x, 
         kent = kf - 1;
     }
     x = 64 * c - 1;
-    if (c == 0) x = 0;
+    if (c == 0) x = klo0 ? 0 : -1;
 }
 
 // Decision words of `ntw` tiles, rows [0, rows_used), from the workspace into the LDS window: 16-byte loads,
@@ -483,6 +494,28 @@ __device__ __forceinline__ void load_window(unsigned *win, int RP, const unsigne
             if (idx < n4) {
                 const int j = idx / q, r4 = idx - j * q;
                 *reinterpret_cast<u32x4 *>(win + j * RP + 4 * r4) = v[k];
+            }
+        }
+    }
+}
+
+// The two-workgroup form's walk: ALL of this half's decision words are in LDS ([ntb tiles][RP], rows numbered from the
+// half's first row), so a window of 64 tiles is a pointer offset -- nothing is loaded between windows, nobody waits at a
+// barrier.  One wave.  Walks rows x .. klo0 from frame e; leaves (first frame) of every walked row in startsLoc[row] and
+// e = the last frame of the row before the lowest one.
+__device__ __forceinline__ void walk_half(const MaxpathParams &p, const unsigned *win, int RP, int ntb, int &x, int &e, int klo0,
+                                          int *startsLoc, int lane) {
+    int startv = 0;
+    for (int jhi = ntb, jb = 0; jhi > 0; jhi = (jb > 0) ? jb + 1 : 0) {
+        jb = (jhi - 64 > 0) ? (jhi - 64) : 0;
+        const int ntw = jhi - jb;
+        if (x >= klo0) {
+            const unsigned *wrow = win + (size_t)(jb + (lane < ntw ? lane : 0)) * RP;
+            int stop = 0;
+            for (int c = x >> 6; c >= 0 && stop == 0; --c) {
+                if (jb == 0) walk_chunk<false>(wrow, c, x, e, startv, lane, 0, ntw, stop, p.status, klo0);
+                else         walk_chunk<true>(wrow, c, x, e, startv, lane, jb, ntw, stop, p.status, klo0);
+                if (stop == 0) startsLoc[64 * c + lane] = startv + 1;
             }
         }
     }
@@ -1174,10 +1207,63 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
         __syncthreads();
     }
     if (PAIR && paired) {
+        // Each half walks its OWN rows (round 4).  The tiles are dead after the sweep and a half's decision words -- 125
+        // tiles x 256 rows at [8,500,4000] -- fit in their place, so: the second half walks rows t_x-1 .. 252 out of its
+        // LDS and hands the frame it arrives at to the first half (one word, xwalk), which has had its own words in
+        // LDS since its sweep ended (it finishes ~20 phases before the second half) and walks rows 251 .. 0; each half
+        // stores the outputs of its rows and frames.  Before, the second half walked all 500 rows over two windows of
+        // 132 KB copied from the workspace between barriers: 28 of the kernel's 106 us.  Not taken (XWALK_SOLO: the
+        // second half does everything, as before) when a non-finite score asks for the exact sweep or the words do
+        // not fit (p.split_walk).  The hand-over word is claimed with compare-and-swap from both sides, so that a first
+        // half that gave up waiting and a second half that arrives late cannot both write outputs.
+        constexpr unsigned XWALK_SOLO = 0xFFFFFFFEu, XWALK_CANCEL = 0xFFFFFFFDu;
+        const int RP2 = row_pitch(256);
+        int *startsL = reinterpret_cast<int *>(smem);
+        unsigned *win2 = reinterpret_cast<unsigned *>(smem) + starts_words_of(p.Tx);
+        int *bcast = startsL + starts_words_of(p.Tx) - 1;               // a word no row owns (the flags' LDS is about to hold decision words)
+        const unsigned *gb = p.bits + (size_t)b * p.NT * p.ROWS;
         if (half == 0) {
             // this half's decision words are written (the barrier waited for every wave's stores): hand them over, with
-            // what its loaders saw, and leave -- the other workgroup finishes the utterance
+            // what its loaders saw
             if (tid == 0) __hip_atomic_store(p.xflag + b, flagp[0] != 0 ? 2 : 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (!p.split_walk) return;                                   // the other workgroup finishes the utterance
+            __threadfence_block();
+            __syncthreads();                                             // (thread 0 has read the flags this copy overwrites)
+            load_window(win2, RP2, gb, p.ROWS, 256, ntb, tid, NW * 128);  // rows 0 .. 255 of every tile
+            if (tid == 0) {
+                unsigned v;
+                int spins = 0;
+                while ((v = __hip_atomic_load(p.xwalk + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == XRING_EMPTY) {
+                    if (++spins > XRING_SPIN_LIMIT) {
+                        unsigned expect = XRING_EMPTY;                   // give up -- unless the word arrives this instant
+                        if (__hip_atomic_compare_exchange_strong(p.xwalk + b, &expect, XWALK_CANCEL, __ATOMIC_RELAXED,
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            atomicOr(p.status, ALIGNER_ST_INTERNAL);
+                            v = XWALK_CANCEL;
+                        } else {
+                            v = expect;
+                        }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                *bcast = (int)v;
+            }
+            __syncthreads();
+            const unsigned hv = (unsigned)*bcast;
+            if (hv >= XWALK_CANCEL) return;      // SOLO: the other half did everything; CANCEL: it will write the all-zero result
+            ALIGNER_STAMP(1);
+            if (wave == 0) {
+                int x = RPW * NW - 1, e = (int)hv;                       // row 251 ends at the frame handed over
+                walk_half(p, win2, RP2, ntb, x, e, 1, startsL, lane);
+                if (x != 0 && lane == 0) atomicOr(p.status, ALIGNER_ST_INTERNAL);
+                if (lane == 0) { startsL[0] = 0; startsL[RPW * NW] = (int)hv + 1; }
+            }
+            ALIGNER_STAMP(3);
+            __syncthreads();
+            store_outputs(p, b, tx, ty, startsL, true, 0, RPW * NW, 0, (int)hv + 1);
+            ALIGNER_STAMP(5);
+            ALIGNER_STAMP(7);
             return;
         }
         if (tid == 0) {
@@ -1191,13 +1277,55 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
         // (thread 0's acquire has invalidated this CU's L1 and the XCD's L2 for everybody; the barrier orders the
         // other waves' loads behind it -- a full fence by all eight waves here cost the kernel 2 us)
         __syncthreads();
-        if (flagp[1] != 0) {
+        const int gave_up = flagp[1], nonfinite = flagp[0];
+        __syncthreads();                                                 // (everybody has read the flags: their LDS may be reused)
+        if (gave_up != 0) {
             // gave up waiting for the first half (ALIGNER_ST_INTERNAL is set): a defined result instead of a path
             // walked over filler -- all-zero path, zero durations, no token on any frame
-            __syncthreads();
+            if (p.split_walk && tid == 0) __hip_atomic_store(p.xwalk + b, XWALK_SOLO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             write_degenerate<MASKMODE, VT>(p, b, MODE_EMPTY, tx, ty, reinterpret_cast<int *>(smem));
             return;
         }
+        if (p.split_walk && !p.force_exact && nonfinite == 0) {
+            const int r0 = RPW * NW;                                     // this half's first row (252)
+            const int rows_loc = ((tx - r0 + 63) / 64) * 64;
+            __threadfence_block();
+            load_window(win2, RP2, gb + r0, p.ROWS, rows_loc, ntb, tid, NW * 128);
+            __syncthreads();
+            ALIGNER_STAMP(1);
+            if (wave == 0) {
+                int x = tx - 1 - r0, e = ty - 1;                         // core.pyx:15
+                walk_half(p, win2, RP2, ntb, x, e, 0, startsL + r0, lane);
+                e = __builtin_amdgcn_readfirstlane(e);
+                if (lane == 0) {
+                    // hand the first half its entry frame -- unless it has given up waiting (then nobody walks its rows)
+                    unsigned expect = XRING_EMPTY;
+                    const bool ok = x == -1 && e >= r0 - 1 &&
+                                    __hip_atomic_compare_exchange_strong(p.xwalk + b, &expect, (unsigned)e, __ATOMIC_RELAXED,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!ok) {
+                        if (expect == XRING_EMPTY)                       // (an inconsistent walk: cannot happen)
+                            __hip_atomic_store(p.xwalk + b, XWALK_SOLO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicOr(p.status, ALIGNER_ST_INTERNAL);
+                    }
+                    *bcast = ok ? 1 : 0;
+                }
+            }
+            ALIGNER_STAMP(3);
+            __syncthreads();
+            if (*bcast == 0) {                                           // the first half is not there: the defined failure
+                __syncthreads();
+                write_degenerate<MASKMODE, VT>(p, b, MODE_EMPTY, tx, ty, reinterpret_cast<int *>(smem));
+                return;
+            }
+            for (int r = tx + tid; r <= p.Tx; r += NW * 128) startsL[r] = ty;
+            __syncthreads();
+            store_outputs(p, b, tx, ty, startsL, true, r0, -1, startsL[r0], -1);
+            ALIGNER_STAMP(5);
+            ALIGNER_STAMP(7);
+            return;
+        }
+        if (p.split_walk && tid == 0) __hip_atomic_store(p.xwalk + b, XWALK_SOLO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // A NaN or an infinity among the scores (or max_neg_val): v_max no longer equals the
     // reference's select, so redo this utterance with the exact barrier-per-frame sweep.
@@ -1355,7 +1483,7 @@ static WsLayout ws_layout(int B, int Tx, int Ty) {
     L.dump_off = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
     // two workgroups per utterance: the boundary row between them, 32 words per tile, and a done word (PAIR)
     L.xring_off = align_up(L.dump_off + (size_t)B * 4 * 64 * sizeof(float), 256);
-    L.xring_bytes = align_up((size_t)B * L.NT * TC * sizeof(unsigned) + (size_t)B * sizeof(int), 256);
+    L.xring_bytes = align_up((size_t)B * L.NT * TC * sizeof(unsigned) + (size_t)2 * B * sizeof(int), 256);   // ring, done words, walk hand-over words
     L.total = L.xring_off + L.xring_bytes;
     return L;
 }
@@ -1511,6 +1639,8 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     if (path_prezeroed && path_done) *path_done = true;
     p.xring = reinterpret_cast<unsigned *>(wsb + L.xring_off);
     p.xflag = reinterpret_cast<int *>(wsb + L.xring_off + (size_t)B * L.NT * TC * sizeof(unsigned));
+    p.xwalk = reinterpret_cast<unsigned *>(p.xflag + B);
+    p.split_walk = 0;
     if (flags & ALIGNER_F_WRITE_Q) {
         if (vt != VT_F32 || (flags & ALIGNER_F_STRICT_MASK))
             return fail(ALIGNER_EINVAL, "ALIGNER_F_WRITE_Q takes fp32 scores without a strict mask (maximum_path_c's contract)");
@@ -1542,6 +1672,13 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
         if (p.WT > 0 && fwd <= lds_max && starts_bytes(Tx) <= fwd) {
             size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
             if (lds < fwd) lds = fwd;
+            // each half walks its own rows when all its decision words (NT tiles x 256 rows) fit in LDS beside the token
+            // starts (see the kernel); "maxpath_no_split_walk" keeps the one-walker form for A/B runs
+            const size_t split_lds = starts_bytes(Tx) + (size_t)L.NT * row_pitch(256) * 4;
+            if (split_lds <= lds_max && !g_opt_maxpath_no_split_walk) {
+                p.split_walk = 1;
+                if (lds < split_lds) lds = split_lds;
+            }
             // the boundary ring and the done words start every launch as 0xFFFFFFFF (a kernel of our own: a captured
             // hipMemsetAsync node did not refill the ring when the graph was replayed)
             const int n16 = (int)(L.xring_bytes / 16);
@@ -1886,7 +2023,7 @@ int aligner_fused_align_f32(const float *keys, const float *queries, const int32
     p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
     p.qout = nullptr;
     p.path1 = nullptr; p.path1_es = 0; p.path1_one = 0;
-    p.xring = nullptr; p.xflag = nullptr;
+    p.xring = nullptr; p.xflag = nullptr; p.xwalk = nullptr; p.split_walk = 0;
     const size_t lds_max = (size_t)lds_limit();
     const FusedLds FL = fused_lds_layout();
     p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);

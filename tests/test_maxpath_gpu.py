@@ -547,6 +547,54 @@ def test_prezeroed_path_at_the_baseline_shapes(appendix_a, dev):
     assert aligner_amd.read_status(dev) == 0
 
 
+def test_two_workgroups_each_half_walks_its_own_rows(dev):
+    """Round 4: in the two-workgroup form each half walks its own rows out of its own LDS (hand-over of one frame number
+    through the workspace) and stores its own part of the outputs.  Same bits as one walker for all rows (the debug option
+    keeps that form) and as the oracle: ragged lengths, tokens hundreds of frames long across the hand-over, the hand-over
+    landing on the first / last frame a row can own, every output dtype of the dense path, token index and durations."""
+    import aligner_amd
+    from aligner_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    cases = [(4, 500, 4000), (3, 300, 2100), (6, 504, 1900), (2, 253, 3000), (5, 420, 2048)]
+    for it, (B, Tx, Ty) in enumerate(cases):
+        v = (rng.standard_normal((B, Tx, Ty)) if it % 2 == 0 else rng.integers(-1, 2, (B, Tx, Ty))).astype(np.float32)
+        ty = rng.integers(max(Tx, Ty // 2), Ty + 1, B).astype(np.int32)
+        ty[0] = Ty
+        tx = np.array([rng.integers(253, min(Tx, t) + 1) for t in ty], np.int32)
+        tx[0] = Tx
+        if B > 2: tx[2] = 253                                               # one row for the second half
+        if B > 3: tx[3] = 200                                               # none: the first workgroup alone
+        v[0, 251, :] += 3.0; v[0, 252, :] += 3.0                             # long tokens either side of the hand-over
+        if B > 1:
+            v[1, :252, :] -= 50.0                                           # the first half's rows as short as they can be:
+            v[1, :252, :252] += 100.0 * np.eye(252, dtype=np.float32)       # the hand-over lands on frame 251
+        want = _oracle_path(v, tx, ty)
+        got = {}
+        for no_split in (0, 1):
+            try:
+                assert lib.aligner_debug_set_option(b"maxpath_no_split_walk", no_split) == 0
+                p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=2)
+            finally:
+                lib.aligner_debug_set_option(b"maxpath_no_split_walk", 0)
+            assert np.array_equal(p, want), (it, no_split)
+            _check_consistency(p, tok, dur, tx, ty)
+            got[no_split] = (tok, dur)
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert aligner_amd.read_status(dev) == 0
+    # the dense path in other dtypes (the zero workgroups ride in the same launch), 16-bit scores
+    B, Tx, Ty = 3, 400, 2000
+    v = rng.standard_normal((B, Tx, Ty)).astype(np.float32)
+    tx = np.array([400, 333, 260], np.int32); ty = np.array([2000, 1999, 1800], np.int32)
+    vb = torch.from_numpy(v).to(dev).to(torch.bfloat16)
+    want = _oracle_path(vb.float().cpu().numpy(), tx, ty)
+    for dt in (torch.float32, torch.uint8, torch.bfloat16, torch.int64):
+        r = aligner_amd.align(vb, torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev), path_dtype=dt, cus_per_utterance=2)
+        assert np.array_equal(r.path.to(torch.int32).cpu().numpy(), want), dt
+        assert np.array_equal(r.durations.cpu().numpy(), want.sum(2))
+    assert aligner_amd.read_status(dev) == 0
+
+
 def test_two_workgroups_full_size_long_form(appendix_a, dev):
     """BASELINE config 5's shape through the form the library picks for it (two workgroups per utterance) and through
     the one-workgroup form: the same path, equal to the reference's hash."""
