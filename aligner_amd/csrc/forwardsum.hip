@@ -1,6 +1,6 @@
 // Forward-sum alignment objective on MI355X (gfx950): the log-likelihood of ALL monotonic alignments
 // and its gradient (the OTA objective the reference's README.md:21-25,50 points at --
-// not in the snapshot, so the spec is build-defined: DESIGN.md 7, oracle/forward_sum_oracle.py).
+// not in the snapshot, so the spec is build-defined: DESIGN.md 5 / DESIGN_HISTORY.md 7, oracle/forward_sum_oracle.py).
 //
 //   alpha[x,y] = logaddexp(alpha[x,y-1], alpha[x-1,y-1]) + logp[x,y]      alpha[0,0] = logp[0,0]
 //   beta [x,y] = logaddexp(beta[x,y+1] + logp[x,y+1], beta[x+1,y+1] + logp[x+1,y+1])   beta[tx-1,ty-1] = 0

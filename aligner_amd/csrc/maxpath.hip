@@ -4,7 +4,7 @@
 //   maximum_path_each  (monotonic_align/core.pyx:7-35)
 //   maximum_path_c     (monotonic_align/core.pyx:38-45)
 // and the marshalling of monotonic_align/__init__.py:11-21, with the score
-// tensor resident in HBM.  See DESIGN.md for the derivation; the short form:
+// tensor resident in HBM.  See DESIGN.md 3 (and DESIGN_HISTORY.md 3 for the derivation); the short form:
 //
 //  * One workgroup per utterance (grid = batch), like the reference's prange.
 //  * The recurrence Q[x,y] = max(Q[x,y-1], Q[x-1,y-1]) + value[x,y] only couples

@@ -1,5 +1,5 @@
 // The two small steps either side of the alignment hot path (not in the reference
-// snapshot -- README.md:21-25,50 only points at the OTA paper -- so the spec is build-defined: DESIGN.md 7,
+// snapshot -- README.md:21-25,50 only points at the OTA paper -- so the spec is build-defined: DESIGN.md 5 / DESIGN_HISTORY.md 7,
 // oracle/forward_sum_oracle.py):
 //
 //   beta-binomial prior   prior[b,x,y] = BetaBinomial(n = t_x, a = s*(y+1), b = s*(t_y-y)).pmf(x)

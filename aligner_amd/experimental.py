@@ -2,7 +2,7 @@
 
 `fused_align` is SURVEY.md 8f rank 1 (similarity -> log-softmax -> alignment search in ONE kernel, the log-probabilities
 consumed from LDS as the matrix cores produce them).  It is built, bit-exact against `align()` on its own log-probs
-(tests/test_fused.py) -- and CLOSED as "measured, loses" (DESIGN.md, section on f1): 126 us against 53 us for the two
+(tests/test_fused.py) -- and CLOSED as "measured, loses" (DESIGN_HISTORY.md 7.2): 126 us against 53 us for the two
 kernels at [64,80,200,1000], 52 against 36 us per step with four batches in flight, because all of `logp` then leaves
 through the 64 CUs the search runs on (800 KB per CU at the 7-11 B/clk a CU stores: 30-47 us by itself).  It is limited to
 C <= 80, T_text <= 252, T_mel <= 2048, no prior.  Use `soft_attention()` + `align()`; import this only to re-measure.

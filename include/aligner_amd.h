@@ -336,7 +336,7 @@ int aligner_fused_align_f32(const float *keys_dev, const float *queries_dev,
                             int B, int C, int Tx, int Ty,
                             float temperature, int sim, float max_neg_val, void *stream);
 
-/* ---- the callers either side of the path (SURVEY.md 8f; build-defined specs, DESIGN.md 7) ---- */
+/* ---- the callers either side of the path (SURVEY.md 8f; build-defined specs, DESIGN.md 5) ---- */
 
 /*
  * Forward-sum alignment objective: loss[b] = -log of the summed likelihood of ALL monotonic

@@ -3,7 +3,7 @@ expanders that sit either side of the hot path.
 
 Parity status: UNPINNED.  None of this is in the reference snapshot (its README only links
 the papers, README.md:49-50, and names the OTA branch, README.md:21-25); the functions below
-restate the published formulation the build adopted:
+restate the published formulation the build adopted (DESIGN_HISTORY.md 7):
 
   forward-sum   the total log-likelihood of all monotonic alignments of `logp[Tx,Ty]` --
                 the column recurrence of maximum_path_each (reference core.pyx:17-30) with
