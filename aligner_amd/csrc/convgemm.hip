@@ -330,23 +330,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
         const int cn = c + 1 < nch ? c + 1 : c;                              // always issue: the counts below stay exact
         stage_x(cn, (c + 1) & 1);                                            // (the last chunk again, into the dead stage)
         const unsigned char *st = cg_smem + (c & 1) * STAGE + lbase;
+        // fragments one frame tile ahead of their MFMAs, ACROSS the taps of the chunk (left alone, hipcc issues a tile's two
+        // reads and waits for the first at once: an LDS round trip per six MFMAs; with the look-ahead restarted per tap a
+        // round trip per tap was exposed: three per chunk)
+        cg_bf16x8 xh = *reinterpret_cast<const cg_bf16x8 *>(st);
+        cg_bf16x8 xl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW) * 16);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // (the chunk's first reads: a group of their own)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             // W[t] of this chunk is the oldest operation in flight; younger: the other taps (4 each), the staging pieces
             cg_wait4<NP + 4 * (KT - 1)>(W[t][0], W[t][1], W[t][2], W[t][3]);
             const cg_bf16x8 wh0 = __builtin_bit_cast(cg_bf16x8, W[t][0]), wl0 = __builtin_bit_cast(cg_bf16x8, W[t][1]);
             const cg_bf16x8 wh1 = __builtin_bit_cast(cg_bf16x8, W[t][2]), wl1 = __builtin_bit_cast(cg_bf16x8, W[t][3]);
-            // fragments one frame tile ahead of their MFMAs (left alone, hipcc issues a tile's two reads and waits for the
-            // first at once: an LDS round trip per six MFMAs)
-            cg_bf16x8 xh = *reinterpret_cast<const cg_bf16x8 *>(st + t * 16);
-            cg_bf16x8 xl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + t) * 16);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);              // (tile 0's reads: a group of their own)
 #pragma unroll
             for (int n = 0; n < FT; ++n) {
                 cg_bf16x8 nh = xh, nl = xl;
                 if (n + 1 < FT) {
                     nh = *reinterpret_cast<const cg_bf16x8 *>(st + (16 * (n + 1) + t) * 16);
                     nl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + 16 * (n + 1) + t) * 16);
+                } else if (t + 1 < KT) {                                     // the next tap's first tile
+                    nh = *reinterpret_cast<const cg_bf16x8 *>(st + (t + 1) * 16);
+                    nl = *reinterpret_cast<const cg_bf16x8 *>(st + (4 * LROW + t + 1) * 16);
                 }
                 acc[0][n] = cg_mfma<SPLIT>(xl, wh0, acc[0][n]);
                 acc[1][n] = cg_mfma<SPLIT>(xl, wh1, acc[1][n]);
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
                 acc[0][n] = cg_mfma<SPLIT>(xh, wh0, acc[0][n]);
                 acc[1][n] = cg_mfma<SPLIT>(xh, wh1, acc[1][n]);
                 // 2 reads, then 6 MFMAs: keep this tile's reads (for the next tile) ahead of this tile's MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // DS read
+                if (n + 1 < FT || t + 1 < KT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
                 __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);          // MFMA
                 xh = nh;
                 xl = nl;
