@@ -942,6 +942,19 @@ def main():
                         "note": "SURVEY 8d: bound by neither HBM nor MFMA -- a dependent chain of T_mel frames on B of the "
                                 "256 CUs; bytes per second are for information"},
                     "dp_wave_occupancy": occ,
+                    # the whole step against the same peak: algorithmic bytes of its three launches over the measured
+                    # time per step on ONE GPU (batches in flight overlap the kernels)
+                    "step_aggregate": {
+                        "algorithmic_bytes": int(sum(v["bytes"] for v in kernels.values())),
+                        "achieved": round(sum(v["bytes"] for v in kernels.values()) / (elapsed / args.steps) / 1e9, 1),
+                        "unit": "GB/s per GPU",
+                        "frac": round(sum(v["bytes"] for v in kernels.values()) / (elapsed / args.steps) / 1e9
+                                      / HBM_PEAK_GBS, 4),
+                        "cu_time_us": round(sum(v["us"] * (min(B, 256) / 256.0 if k == longest else 1.0)
+                                                for k, v in kernels.items()), 2),
+                        "note": "cu_time_us = sum of the kernels' durations weighted by the share of the 256 CUs each one "
+                                "occupies (the search: B of them): the step cannot be shorter than that however the batches "
+                                "in flight interleave"},
                     "all_kernels": {k: {"us": round(v["us"], 2),
                                         "GBps": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1),
                                         "frac_of_8000": round(v["bytes"] / (v["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3),
