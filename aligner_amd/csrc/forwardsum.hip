@@ -57,6 +57,7 @@ struct FwdSumParams {
     float  *loss;           // [B]
     float  *grad;           // [B,Tx,Ty] (backward only)
     int B, Tx, Ty, NT;
+    double *doffs;          // workspace [B,SY_NW_MAX,NT]: D_w per (wave, frame) -- the sweeps-side-by-side form only
 };
 
 // log2(2^a + 2^b).  The log term is in (0, 1]: its absolute error (~1 ulp of the hardware log2/exp2)
@@ -375,13 +376,13 @@ constexpr int SY_NW_MAX = 8;                       // offsets in the workspace: 
 // 16-wave workgroup has 128 VGPRs per lane and the backward kernel four tile arrays in LDS)
 
 template <int SY_NW, int SY_TW>
-__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdSumParams p) {
+__device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, const int b) {
     constexpr int SY_TILE = SY_TW * SY_LD;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     float *tin = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
     float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha
     double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1);
     const bool sweeper = wave < SY_NW;
@@ -503,7 +504,16 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
 }
 
 template <int SY_NW, int SY_TW>
-__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(FwdSumParams p) {
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdSumParams p) {
+    fwdsum_forward_sys_body<SY_NW, SY_TW>(p, blockIdx.x);
+}
+
+// BETA_ONLY: the sweep alone, for the form in which it runs BESIDE the forward sweep (fwdsum_both_sys_kernel: alpha and
+// beta do not depend on each other, only the posterior needs both): no alpha, no offsets, no log Z come in; what goes out
+// through the gradient tile is beta itself, relative to the wave's offset of that frame (D_w[y], to p.doffs), into
+// p.grad -- which fwdsum_combine_kernel then turns into the gradient in place.
+template <int SY_NW, int SY_TW, bool BETA_ONLY>
+__device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, const int b) {
     constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
     float *tlp = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
     float *tg = tgr + SY_NW * 2 * SY_TILE;                    // g = beta + logp (relative to D_w): slot 0 feeds the wave above
     double *toff = reinterpret_cast<double *>(tg + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
     double *tdof = toff + SY_NW * 2 * SY_TW;                  // [NW][2][TW] D_w per frame
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
     const bool sweeper = wave < SY_NW;
@@ -523,11 +533,14 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
     const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0;
     // frames past the utterance's last tile (everything when no alignment exists): gradient 0
-    for (int r = 0; r < p.Tx; ++r)
-        for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
+    // (BETA_ONLY: fwdsum_combine_kernel writes every element of the gradient)
+    if (!BETA_ONLY)
+        for (int r = 0; r < p.Tx; ++r)
+            for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
     if (!ok) return;
-    const double logz = p.logz[b];
+    const double logz = BETA_ONLY ? 0.0 : p.logz[b];
     const double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
+    double *doffs = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
     float g_prev = FS_NEG;                                    // beta[x,y+1] + logp[x,y+1], relative to D
     const bool ghost = lane == 63, rowok = row < tx;
@@ -549,10 +562,10 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                 rg = rg < tx ? rg : tx - 1;
                 const int yc = y0 + c < ty ? y0 + c : ty - 1;
                 vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-                unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+                if (!BETA_ONLY) unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
             }
             const int yo = y0 + (lane & (SY_TW - 1));
-            onext = offs[yo < ty ? yo : ty - 1];
+            if (!BETA_ONLY) onext = offs[yo < ty ? yo : ty - 1];
         };
         stage_issue(0);
         for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
@@ -564,9 +577,9 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
                     dlp[c * SY_LD + r] = fs_in(vnext[i]);
-                    dal[c * SY_LD + r] = unext[i];
+                    if (!BETA_ONLY) dal[c * SY_LD + r] = unext[i];
                 }
-                if (lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
+                if (!BETA_ONLY && lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
                 stage_issue(kl + 1);
             }
             if (ks >= 0 && ks < ntl) {
@@ -578,6 +591,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                     const int rg = 63 * w + r;
                     if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
                 }
+                if (BETA_ONLY && lane < SY_TW && y0 + lane < ty) doffs[y0 + lane] = tdof[(w * 2 + (ks & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
         }
@@ -600,8 +614,8 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                 double cov[SY_TW], dpv[SY_TW];
 #pragma unroll
                 for (int c = 0; c < SY_TW; ++c) {
-                    lpv[c] = slp[c * SY_LD]; alv[c] = sal[c * SY_LD]; rgv[c] = ring[c * SY_LD];
-                    cov[c] = myoff[c]; dpv[c] = dp[c];
+                    lpv[c] = slp[c * SY_LD]; rgv[c] = ring[c * SY_LD]; dpv[c] = dp[c];
+                    if (!BETA_ONLY) { alv[c] = sal[c * SY_LD]; cov[c] = myoff[c]; }
                 }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
@@ -612,14 +626,18 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
                             dgr[c * SY_LD] = 0.f;
                             continue;
                         }
-                        const float lp = lpv[c], al = alv[c];
-                        const float st = (float)(cov[c] + Dl);                       // C_w[y] + D_w - log Z, uniform
+                        const float lp = lpv[c];
                         const float dn = fs_from_lane_above(FS_NEG, g_prev);          // row below
                         float beta;
                         if (TAIL && y == ty - 1) beta = (row == tx - 1) ? 0.f : FS_NEG;   // uniform branch
                         else                     beta = fs_lae2(g_prev, dn);
                         beta = rowok ? beta : FS_NEG;
-                        dgr[c * SY_LD] = -__builtin_amdgcn_exp2f(al + beta + st);     // 2^(-1e30) = 0
+                        if (BETA_ONLY) {
+                            dgr[c * SY_LD] = beta - drift;            // relative to the D recorded for this frame (D + drift)
+                        } else {
+                            const float st = (float)(cov[c] + Dl);                   // C_w[y] + D_w - log Z, uniform
+                            dgr[c * SY_LD] = -__builtin_amdgcn_exp2f(alv[c] + beta + st);   // 2^(-1e30) = 0
+                        }
                         float g = fmaxf(beta + (lp - drift), FS_NEG);
                         D += drift_d;
                         Dl += drift_d;
@@ -646,6 +664,59 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(Fwd
             fs_lds_barrier();
         }
     }
+}
+
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(FwdSumParams p) {
+    fwdsum_backward_sys_body<SY_NW, SY_TW, false>(p, blockIdx.x);
+}
+
+// The two sweeps side by side (2B workgroups <= the CUs): alpha runs forward and beta backward through the same log-probs
+// and neither reads the other -- only the posterior needs both.  Even blocks sweep alpha (loss, log Z, alpha and its
+// offsets into the workspace, exactly fwdsum_forward_sys_kernel), odd blocks beta (into the gradient buffer, offsets
+// into p.doffs); fwdsum_combine_kernel then makes the gradient of it in place.  One launch of ~max(forward, backward)
+// plus one streaming pass instead of forward + backward one after the other on a quarter of the chip.
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_both_sys_kernel(FwdSumParams p) {
+    const int b = blockIdx.x >> 1;
+    if (blockIdx.x & 1) fwdsum_backward_sys_body<SY_NW, SY_TW, true>(p, b);
+    else                fwdsum_forward_sys_body<SY_NW, SY_TW>(p, b);
+}
+
+// gradient = -posterior = -2^(alpha + beta - log Z), in place over the beta the sweep left in p.grad: four frames of one
+// text row per thread (16-byte accesses when T_mel allows), the offsets of the row's wave (C_w forward, D_w backward:
+// one pair per frame, shared by the wave's 63 rows -- L2 hits).  Rows >= t_x, frames >= t_y, utterances without an
+// alignment: 0.
+__global__ __launch_bounds__(256) void fwdsum_combine_kernel(FwdSumParams p) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y0 >= p.Ty) return;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t o = ((size_t)b * p.Tx + r) * p.Ty + y0;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = p.Ty - y0 < 4 ? p.Ty - y0 : 4;
+    const bool vec = n == 4 && ((reinterpret_cast<uintptr_t>(p.alpha + o) | reinterpret_cast<uintptr_t>(p.grad + o)) & 15) == 0;
+    if (ok && r < tx && y0 < ty) {
+        const int w = r / 63;
+        const double *C = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
+        const double *D = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
+        const double lz = p.logz[b];
+        float al[4], be[4];
+        if (vec) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(p.alpha + o), b4 = *reinterpret_cast<const float4 *>(p.grad + o);
+            al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+            be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
+        } else {
+            for (int j = 0; j < n; ++j) { al[j] = p.alpha[o + j]; be[j] = p.grad[o + j]; }
+        }
+        for (int j = 0; j < n; ++j)
+            if (y0 + j < ty) g[j] = -__builtin_amdgcn_exp2f(al[j] + be[j] + (float)(C[j] + D[j] - lz));
+    }
+    if (vec) *reinterpret_cast<float4 *>(p.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
+    else for (int j = 0; j < n; ++j) p.grad[o + j] = g[j];
 }
 
 // --------------------------------------------------------------------------
@@ -980,7 +1051,7 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_ctc_backward_kernel(CtcPara
 // workspace, same numerics as the one-wave kernels above.
 // --------------------------------------------------------------------------
 template <int SY_NW, int SY_TW>
-__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(CtcParams q) {
+__device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, const int b) {
     const FwdSumParams &p = q.f;
     constexpr int SY_TILE = SY_TW * SY_LD;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
@@ -988,7 +1059,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(
     float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha of the token states
     double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
     double *tns = toff + SY_NW * 2 * SY_TW;                   // [TW] partial sums of the frames' normalisers
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1);
     const bool sweeper = wave < SY_NW;
@@ -1118,7 +1189,14 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(
 }
 
 template <int SY_NW, int SY_TW>
-__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel(CtcParams q) {
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(CtcParams q) {
+    fwdsum_ctc_forward_sys_body<SY_NW, SY_TW>(q, blockIdx.x);
+}
+
+// BETA_ONLY as in fwdsum_backward_sys_body: the token states' beta (relative to D_w[y], which goes to p.doffs) leaves
+// through the gradient tile into p.grad; fwdsum_ctc_combine_kernel makes the gradient of it.
+template <int SY_NW, int SY_TW, bool BETA_ONLY>
+__device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q, const int b) {
     const FwdSumParams &p = q.f;
     constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
@@ -1130,7 +1208,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
     float2 *tg = reinterpret_cast<float2 *>(tdof + SY_NW * 2 * SY_TW);     // [NW][2][TW] (g_B, g_T) of a wave's FIRST row
     float *tnrm = reinterpret_cast<float *>(tg + SY_NW * 2 * SY_TW);       // [NW][2][TW] n_y
     float2 *dump = reinterpret_cast<float2 *>(tnrm + SY_NW * 2 * SY_TW);   // [NW][64] where the other lanes write
-    const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
     const bool sweeper = wave < SY_NW;
@@ -1140,11 +1218,13 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
     const bool ok = tx >= 1 && tx <= ty;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
     const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0;
-    for (int r = 0; r < p.Tx; ++r)
-        for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
+    if (!BETA_ONLY)
+        for (int r = 0; r < p.Tx; ++r)
+            for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
     if (!ok) return;
-    const double logz = p.logz[b];
+    const double logz = BETA_ONLY ? 0.0 : p.logz[b];
     const double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
+    double *doffs = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
     float gT = FS_NEG, gB = FS_NEG;                           // beta + emission of frame y+1, relative to D
     const bool ghost = lane == 63, okT = row < tx, okB = row <= tx;
@@ -1164,11 +1244,13 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                 rg = rg < tx ? rg : tx - 1;
                 const int yc = y0 + c < ty ? y0 + c : ty - 1;
                 vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-                unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+                if (!BETA_ONLY) unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
             }
             const int yo = y0 + (lane & (SY_TW - 1));
-            onext = offs[yo < ty ? yo : ty - 1];
-            nnext = q.nrm[(size_t)b * p.Ty + (yo < ty ? yo : ty - 1)];
+            if (!BETA_ONLY) {
+                onext = offs[yo < ty ? yo : ty - 1];
+                nnext = q.nrm[(size_t)b * p.Ty + (yo < ty ? yo : ty - 1)];
+            }
         };
         stage_issue(0);
         for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
@@ -1180,9 +1262,9 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
                     dlp[c * SY_LD + r] = fs_in(vnext[i]);
-                    dal[c * SY_LD + r] = unext[i];
+                    if (!BETA_ONLY) dal[c * SY_LD + r] = unext[i];
                 }
-                if (lane < SY_TW) {
+                if (!BETA_ONLY && lane < SY_TW) {
                     toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
                     tnrm[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? nnext : 0.f;
                 }
@@ -1197,6 +1279,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                     const int rg = 63 * w + r;
                     if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
                 }
+                if (BETA_ONLY && lane < SY_TW && y0 + lane < ty) doffs[y0 + lane] = tdof[(w * 2 + (ks & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
         }
@@ -1221,8 +1304,8 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                 double cov[SY_TW], dpv[SY_TW];
 #pragma unroll
                 for (int c = 0; c < SY_TW; ++c) {
-                    xv[c] = slp[c * SY_LD]; alv[c] = sal[c * SY_LD]; rgv[c] = ring[c];
-                    cov[c] = myoff[c]; dpv[c] = dp[c]; nyv[c] = mynrm[c];
+                    xv[c] = slp[c * SY_LD]; rgv[c] = ring[c]; dpv[c] = dp[c];
+                    if (!BETA_ONLY) { alv[c] = sal[c * SY_LD]; cov[c] = myoff[c]; nyv[c] = mynrm[c]; }
                 }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
@@ -1233,8 +1316,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                             dgr[c * SY_LD] = 0.f;
                             continue;
                         }
-                        const float x = xv[c], al = alv[c];
-                        const float st = (float)(cov[c] + Dl);                       // C_w[y] + D_w - log Z, uniform
+                        const float x = xv[c];
                         const float aB = fs_from_lane_above(FS_NEG, gB);             // the row below
                         const float aT = fs_from_lane_above(FS_NEG, gT);
                         float bT, bB;
@@ -1247,8 +1329,13 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
                         }
                         bT = okT ? bT : FS_NEG;
                         bB = okB ? bB : FS_NEG;
-                        const float occ = __builtin_amdgcn_exp2f(al + bT + st);      // 2^(-1e30) = 0
-                        dgr[c * SY_LD] = okT ? __builtin_amdgcn_exp2f(x - nyv[c]) - occ : 0.f;
+                        if (BETA_ONLY) {
+                            dgr[c * SY_LD] = bT - drift;              // relative to the D recorded for this frame (D + drift)
+                        } else {
+                            const float st = (float)(cov[c] + Dl);                   // C_w[y] + D_w - log Z, uniform
+                            const float occ = __builtin_amdgcn_exp2f(alv[c] + bT + st);   // 2^(-1e30) = 0
+                            dgr[c * SY_LD] = okT ? __builtin_amdgcn_exp2f(x - nyv[c]) - occ : 0.f;
+                        }
                         float nT = fmaxf(bT + (x - drift), FS_NEG);
                         float nB = fmaxf(bB + (q.blank2 - drift), FS_NEG);
                         D += drift_d;
@@ -1282,7 +1369,61 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
     }
 }
 
-struct FsLayout { size_t alpha_off, offs_off, logz_off, total; int NT, R; };
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel(CtcParams q) {
+    fwdsum_ctc_backward_sys_body<SY_NW, SY_TW, false>(q, blockIdx.x);
+}
+
+// the CTC form's sweeps side by side (see fwdsum_both_sys_kernel) ...
+template <int SY_NW, int SY_TW>
+__global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_both_sys_kernel(CtcParams q) {
+    const int b = blockIdx.x >> 1;
+    if (blockIdx.x & 1) fwdsum_ctc_backward_sys_body<SY_NW, SY_TW, true>(q, b);
+    else                fwdsum_ctc_forward_sys_body<SY_NW, SY_TW>(q, b);
+}
+
+// ... and its gradient, in place over the token states' beta: softmax over blank + text of the frame minus the token's
+// occupancy, d loss / d x[r,y] = 2^(x[r,y] - n_y) - 2^(alpha + beta - log Z)   (fwdsum_ctc_backward_sys_body's line).
+__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) {
+    const FwdSumParams &p = q.f;
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (y0 >= p.Ty) return;
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    const bool ok = tx >= 1 && tx <= ty;
+    const size_t o = ((size_t)b * p.Tx + r) * p.Ty + y0;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    const int n = p.Ty - y0 < 4 ? p.Ty - y0 : 4;
+    const bool vec = n == 4 && ((reinterpret_cast<uintptr_t>(p.alpha + o) | reinterpret_cast<uintptr_t>(p.grad + o) |
+                                 reinterpret_cast<uintptr_t>(p.logp + o)) & 15) == 0;
+    if (ok && r < tx && y0 < ty) {
+        const int w = r / 63;
+        const double *C = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
+        const double *D = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
+        const float *ny = q.nrm + (size_t)b * p.Ty + y0;
+        const double lz = p.logz[b];
+        float al[4], be[4], x[4];
+        if (vec) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(p.alpha + o), b4 = *reinterpret_cast<const float4 *>(p.grad + o);
+            const float4 x4 = *reinterpret_cast<const float4 *>(p.logp + o);
+            al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+            be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
+            x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
+        } else {
+            for (int j = 0; j < n; ++j) { al[j] = p.alpha[o + j]; be[j] = p.grad[o + j]; x[j] = p.logp[o + j]; }
+        }
+        for (int j = 0; j < n; ++j)
+            if (y0 + j < ty)
+                g[j] = __builtin_amdgcn_exp2f(fs_in(x[j]) - ny[j]) -
+                       __builtin_amdgcn_exp2f(al[j] + be[j] + (float)(C[j] + D[j] - lz));
+    }
+    if (vec) *reinterpret_cast<float4 *>(p.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
+    else for (int j = 0; j < n; ++j) p.grad[o + j] = g[j];
+}
+
+struct FsLayout { size_t alpha_off, offs_off, logz_off, doffs_off, total; int NT, R; };
 
 static FsLayout fs_layout(int B, int Tx, int Ty) {
     FsLayout L;
@@ -1291,7 +1432,8 @@ static FsLayout fs_layout(int B, int Tx, int Ty) {
     L.alpha_off = 0;
     L.offs_off = align_up((size_t)B * Tx * Ty * sizeof(float), 256);
     L.logz_off = L.offs_off + align_up((size_t)B * SY_NW_MAX * L.NT * sizeof(double), 256);   // per (wave, frame)
-    L.total = L.logz_off + align_up((size_t)B * sizeof(double), 256);
+    L.doffs_off = L.logz_off + align_up((size_t)B * sizeof(double), 256);
+    L.total = L.doffs_off + align_up((size_t)B * SY_NW_MAX * L.NT * sizeof(double), 256);   // backward offsets, sweeps side by side
     return L;
 }
 
@@ -1313,6 +1455,11 @@ static int fs_launch(const FwdSumParams &p, bool backward, hipStream_t s) {
     return ALIGNER_OK;
 }
 
+// Both sweeps in one launch pay when all 2B workgroups are resident at once, one per CU (measured at [B,200,1000]: B = 16
+// 106 us, 64 133 us against 215 one after the other; B = 128, exactly one workgroup per CU, 238: a single workgroup that
+// has to wait for a CU doubles the launch): up to three quarters of the CUs.
+static bool fs_side_by_side(int B) { return 8 * B <= 3 * device_cu_count(); }
+
 template <int SY_NW, int SY_TW>
 static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
     constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
@@ -1320,6 +1467,17 @@ static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
     const size_t lds_b = (size_t)4 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double);
     auto kf = fwdsum_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_backward_sys_kernel<SY_NW, SY_TW>;
+    // with the gradient, on a batch that leaves half the CUs idle: both sweeps in one launch, then the combining pass
+    if (backward && !g_opt_fwdsum_serial && fs_side_by_side(p.B) && p.doffs) {
+        auto k2 = fwdsum_both_sys_kernel<SY_NW, SY_TW>;
+        const size_t lds = lds_f > lds_b ? lds_f : lds_b;
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
+        hipLaunchKernelGGL(k2, dim3(2 * p.B), dim3(SY_THREADS), lds, s, p);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(fwdsum_combine_kernel, dim3((p.Ty + 1023) / 1024, p.Tx, p.B), dim3(256), 0, s, p);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        return ALIGNER_OK;
+    }
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
     hipLaunchKernelGGL(kf, dim3(p.B), dim3(SY_THREADS), lds_f, s, p);
     ALIGNER_HIP_CHECK(hipGetLastError());
@@ -1361,6 +1519,16 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
     ALIGNER_HIP_CHECK(hipGetLastError());
     auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_ctc_backward_sys_kernel<SY_NW, SY_TW>;
+    if (backward && !g_opt_fwdsum_serial && fs_side_by_side(q.f.B) && q.f.doffs) {
+        auto k2 = fwdsum_ctc_both_sys_kernel<SY_NW, SY_TW>;
+        const size_t lds = lds_f > lds_b ? lds_f : lds_b;
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
+        hipLaunchKernelGGL(k2, dim3(2 * q.f.B), dim3(SY_THREADS), lds, s, q);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 1023) / 1024, q.f.Tx, q.f.B), dim3(256), 0, s, q);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        return ALIGNER_OK;
+    }
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
     hipLaunchKernelGGL(kf, dim3(q.f.B), dim3(SY_THREADS), lds_f, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
@@ -1395,7 +1563,7 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     FwdSumParams p{logp, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off),
                    reinterpret_cast<double *>(ws + L.offs_off), reinterpret_cast<double *>(ws + L.logz_off),
-                   loss_out, grad_out, B, Tx, Ty, L.NT};
+                   loss_out, grad_out, B, Tx, Ty, L.NT, reinterpret_cast<double *>(ws + L.doffs_off)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
     if (!g_opt_fwdsum_one_wave) {
@@ -1426,7 +1594,8 @@ int aligner_forward_sum_ctc_f32(const float *scores, const int32_t *t_xs, const 
     if (workspace_bytes < total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, total);
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     CtcParams q{{scores, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off), reinterpret_cast<double *>(ws + L.offs_off),
-                 reinterpret_cast<double *>(ws + L.logz_off), loss_out, grad_out, B, Tx, Ty, L.NT},
+                 reinterpret_cast<double *>(ws + L.logz_off), loss_out, grad_out, B, Tx, Ty, L.NT,
+                 reinterpret_cast<double *>(ws + L.doffs_off)},
                 reinterpret_cast<float *>(ws + L.total), blank_logprob * FS_LOG2E};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;

@@ -299,3 +299,40 @@ def test_forward_sum_ctc_form_degenerate_and_loss_only(dev):
     assert abs(float(loss[0]) - want[0]) < 1e-4 and torch.isinf(loss[1]) and torch.isinf(loss[2])
     assert not grad[1].any() and not grad[2].any()
     assert np.abs(grad[0].cpu().numpy() - wgrad[0]).max() < 1e-4
+
+
+# With the gradient asked for, a batch that leaves the CUs half idle runs both sweeps in ONE launch (alpha and beta do not
+# read each other) and a combining pass; larger batches, or the debug option, run forward then backward.  Same numbers up
+# to fp32 rounding of the exponent's sum; degenerate utterances and the padding are zeros either way.
+@gpu
+@pytest.mark.parametrize("blank", [None, -1.0])
+@pytest.mark.parametrize("B,Tx,Ty", [(5, 40, 130), (3, 200, 1000), (2, 251, 517), (2, 300, 702), (100, 20, 64)])
+def test_forward_sum_side_by_side_sweeps_equal_the_serial_form(dev, request, B, Tx, Ty, blank):
+    import aligner_amd
+    from aligner_amd import _lib
+    rng = np.random.default_rng(B + 31 * Tx)
+    lp = torch.from_numpy(_rand_logp(rng, B, Tx, Ty)).to(dev)
+    ty = rng.integers(max(Tx // 2, 2), Ty + 1, size=B)
+    tx = np.minimum(rng.integers(1, Tx + 1, size=B), ty)
+    tx[0], ty[0] = Tx, Ty
+    if B > 2:
+        tx[1], ty[1] = min(Tx, 9), 5                              # fewer frames than tokens: loss +inf, gradient 0
+    tx, ty = torch.from_numpy(tx), torch.from_numpy(ty)
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"fwdsum_serial", 0))
+    _lib.check(lib.aligner_debug_set_option(b"fwdsum_serial", 1))
+    loss_s, grad_s = aligner_amd.forward_sum(lp, tx, ty, blank_logprob=blank)
+    grad_s = grad_s.clone()
+    _lib.check(lib.aligner_debug_set_option(b"fwdsum_serial", 0))
+    loss_p, grad_p = aligner_amd.forward_sum(lp, tx, ty, blank_logprob=blank)
+    torch.cuda.synchronize()
+    assert torch.equal(loss_s, loss_p)                            # the forward sweep is the same code
+    # (both forms add alpha, beta and the offsets in fp32, in a different order: at |alpha| ~ 300 below its wave's column
+    # maximum one rounding is 3e-5 of the posterior -- a fifth of the tolerance against the oracle)
+    # (the CTC form's gradient is softmax - occupancy: the same relative rounding of an occupancy of up to 1, absolute)
+    tol_abs = 2e-6 if blank is None else 2e-4
+    assert bool(((grad_s - grad_p).abs() <= 2e-4 * grad_s.abs() + tol_abs).all()), float((grad_s - grad_p).abs().max())
+    for b in range(B):
+        assert not grad_p[b, int(tx[b]):].any() and not grad_p[b, :, int(ty[b]):].any()
+    if B > 2:
+        assert not grad_p[1].any() and torch.isinf(loss_p[1])
