@@ -50,6 +50,7 @@ extern int g_opt_mobo_full_chain;      // "mobo_full_chain": testing, the search
 extern int g_opt_conv_narrow_ft;      // "conv_narrow_ft": testing, frame tiles (8, 4, 2) per workgroup of the narrow conv kernel (0: the plan's choice)
 extern int g_opt_maxpath_no_split_walk;   // "maxpath_no_split_walk": A-B / testing, the two-workgroup search with one walker (the second half) for all rows
 extern int g_opt_conv_no_fuse;        // "conv_no_fuse": testing / A-B, a stack's trailing narrow layers as separate kernels instead of conv_narrow_fused_kernel
+extern int g_opt_conv_split_always;    // "conv_split_always": narrow layers never stage fp32 themselves (A/B, tests)
 extern int g_opt_softattn_split;       // "softattn_split": development, waves per strip of the row-group form (2, 4; 1: at most 2; 0: the launch's choice)
 extern int g_opt_softattn_no_pair;     // "softattn_no_pair": testing, the similarity kernel's row-group form with one wave per strip only
 extern int g_opt_mobo_bwd_general;     // "mobo_bwd_general": testing, the gradient's chain in its general (one exp2 per term) form

@@ -145,6 +145,8 @@ struct ConvGemmParams {
     unsigned long long xs_plane, ys_plane;
     int B, Cout, T, S, nch, cpad, relu, nx;
     int S2, nch2;           // SPLIT: slots per row and 32-channel chunks of the next layer's image
+    const float *xf;        // narrow forms: the activations as fp32 [B, Cin, T] instead of xs (staged and split by the kernel)
+    int Cin;                // ... and their channel count
 };
 
 #ifndef CG_DMA_BITS
@@ -519,6 +521,56 @@ __device__ __forceinline__ void cn_stage_all(const uint4 *xs, unsigned long long
     }
 }
 
+// The same LDS image straight from fp32 activations [B, Cin, T]: a narrow layer at the head of a stack (the mel encoder's
+// first) needs no split pass over HBM -- its workgroup reads each input element once anyway.  One item = 8 input channels
+// of one slot (what conv_split_kernel's thread does), four items' loads in flight per thread; consecutive lanes take
+// consecutive frames (256-byte row segments in, 16-byte ds_writes out, 1 KB contiguous per wave and plane).
+template <int KT, int FT>
+__device__ __forceinline__ void cn_stage_f32(const float *__restrict__ x, int Cin, int T, int nch, int b, int f0, int tid,
+                                             int nthreads, unsigned char *lds) {
+    constexpr int LROW = cg_lrow(KT, FT), HALO = KT / 2, U = 4;
+    const int items = nch * 4 * LROW;
+    const float *xb = x + (size_t)b * Cin * T;
+    uint4 *img = reinterpret_cast<uint4 *>(lds);
+    for (int it0 = tid; it0 < items; it0 += U * nthreads) {
+        float v[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * nthreads;
+            const int itc = it < items ? it : items - 1;
+            const int sl = itc % LROW, cq = itc / LROW;
+            const int t = f0 + sl - HALO;
+            const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = 8 * cq + j;                                       // 32 * chunk + 8 * quarter + j
+                v[u][j] = xb[(size_t)(i < Cin ? i : Cin - 1) * T + tc];        // unconditional, masked below
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int it = it0 + u * nthreads;
+            if (it < items) {
+                const int sl = it % LROW, cq = it / LROW;
+                const int t = f0 + sl - HALO;
+                const bool in = t >= 0 && t < T;
+                cg_bf16x8 hv, lv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    __bf16 hh, ll;
+                    cg_split((in && 8 * cq + j < Cin) ? v[u][j] : 0.f, hh, ll);
+                    hv[j] = hh;
+                    lv[j] = ll;
+                }
+                uint4 *d = img + ((size_t)(cq >> 2) * 8 + (cq & 3)) * LROW + sl;   // [chunk][plane][quarter][slot]
+                d[0] = __builtin_bit_cast(uint4, hv);
+                d[4 * LROW] = __builtin_bit_cast(uint4, lv);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // the ds_writes, before the caller's barrier
+}
+
 template <int KT, int FT, int NT, bool SPLIT>
 __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
@@ -528,7 +580,8 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
     const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
     const int f0 = bx * 16 * FT;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
-    cn_stage_all<KT, FT>(p.xs, p.xs_plane, p.S, p.nch, b, f0, wave, nw, lane, lds0);
+    if (p.xf) cn_stage_f32<KT, FT>(p.xf, p.Cin, p.T, p.nch, b, f0, tid, (int)blockDim.x, cg_smem);
+    else      cn_stage_all<KT, FT>(p.xs, p.xs_plane, p.S, p.nch, b, f0, wave, nw, lane, lds0);
     CnRing<NT> R;
     R.init(p.wp, p.cpad, p.nch * KT, wave, lane, (int)blockIdx.x);
     R.prime();
@@ -558,6 +611,7 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
 struct FusedLayer { const uint4 *wp; const float *bias; int nch, cpad, Cout, relu; };
 struct ConvFusedParams {
     const uint4 *xs; unsigned long long xs_plane; int S, nx;
+    const float *xf; int Cin0;   // the first layer's input as fp32 [B, Cin0, T] instead of xs (see cn_stage_f32)
     FusedLayer L[3];
     ConvGemmParams out;       // the last layer's epilogue (bias, relu, Cout, T, y)
     int ldsB;                 // byte offset of the second LDS buffer
@@ -644,7 +698,8 @@ __global__ __launch_bounds__(768) void conv_narrow_fused_kernel(ConvFusedParams 
     unsigned char *bufA = cg_smem, *bufB = cg_smem + p.ldsB;
     const unsigned xoff = (unsigned)n0 * 256u;           // this wave's first frame tile inside an image row
     CF_STAMP(0);
-    cn_stage_all<KT0, FT>(p.xs, p.xs_plane, p.S, p.L[0].nch, b, f0, wave, nw, lane, lds0);
+    if (p.xf) cn_stage_f32<KT0, FT>(p.xf, p.Cin0, p.out.T, p.L[0].nch, b, f0, tid, (int)blockDim.x, cg_smem);
+    else      cn_stage_all<KT0, FT>(p.xs, p.xs_plane, p.S, p.L[0].nch, b, f0, wave, nw, lane, lds0);
     CnRing<N0, CN_RING> R0;
     R0.init(p.L[0].wp, p.L[0].cpad, p.L[0].nch * KT0, wt, lane, (int)blockIdx.x);
     R0.prime();
@@ -911,15 +966,26 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
         return ALIGNER_OK;
     };
     int cur = 0;
-    int rc = split_pass(x, bufs[0], L[0].Cin, L[0].K);
-    if (rc != ALIGNER_OK) return rc;
+    int rc = ALIGNER_OK;
+    // the current activations are either fp32 (`f32`: the caller's x, or a layer's fp32 output) or a split image in
+    // bufs[cur]; a narrow layer stages fp32 itself (cn_stage_f32), a wide one needs the split pass first
+    const float *f32 = x;
+    const bool stage_f32 = !g_opt_conv_split_always;
     const FusedPlan F = fused_plan(L, n, B, T);
     for (int i = 0; i < n; ++i) {
-        if (F.count && i == n - F.count) {                                   // the stack's last layers: one kernel, tiles kept on the CU
+        const bool fused_here = F.count && i == n - F.count;
+        const bool narrow_here = fused_here || conv_plan(B, L[i].Cin, L[i].Cout, T, L[i].K).form == CG_NARROW;
+        if (f32 && !(narrow_here && stage_f32)) {
+            rc = split_pass(f32, bufs[cur], L[i].Cin, L[i].K);               // (a layer that read bufs[cur] is behind us: stream order)
+            if (rc != ALIGNER_OK) return rc;
+            f32 = nullptr;
+        }
+        if (fused_here) {                                                    // the stack's last layers: one kernel, tiles kept on the CU
             const ConvStackLayer *G = L + i;
             ConvFusedParams fp{};
             const int nch0 = (G[0].Cin + CG_CH - 1) / CG_CH, S0 = (T + 2 * (G[0].K / 2) + 15) / 16 * 16;
             fp.stamps = g_debug_stamps;
+            fp.xf = f32; fp.Cin0 = G[0].Cin;
             fp.xs = bufs[cur]; fp.xs_plane = (unsigned long long)B * nch0 * 4 * S0; fp.S = S0; fp.nx = F.nx; fp.ldsB = (int)F.ldsB;
             for (int j = 0; j < F.count; ++j)
                 fp.L[j] = FusedLayer{static_cast<const uint4 *>(G[j].prepared), G[j].bias, (G[j].Cin + CG_CH - 1) / CG_CH,
@@ -942,6 +1008,8 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
         const bool last = i + 1 == n;
         const bool split = !last && L[i + 1].K == 1;                         // write the consumer's image directly
         ConvGemmParams p{};
+        p.xf = f32; p.Cin = L[i].Cin;
+        f32 = nullptr;
         p.xs = bufs[cur]; p.wp = static_cast<const uint4 *>(L[i].prepared); p.bias = L[i].bias;
         p.xs_plane = (unsigned long long)B * nch * 4 * S;
         p.B = B; p.Cout = L[i].Cout; p.T = T; p.S = S; p.nch = nch; p.relu = L[i].relu;
@@ -956,12 +1024,8 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
         rc = conv_launch(P, p, L[i].K, split, s);
         if (rc != ALIGNER_OK) return rc;
         if (getenv("ALIGNER_CONV_SYNC")) (void)hipStreamSynchronize(s);
-        if (split) {
-            cur ^= 1;
-        } else if (!last) {
-            rc = split_pass(tmp, bufs[cur], L[i + 1].Cin, L[i + 1].K);     // (this layer has read bufs[cur]: stream order)
-            if (rc != ALIGNER_OK) return rc;
-        }
+        if (split) cur ^= 1;
+        else if (!last) f32 = tmp;
     }
     return ALIGNER_OK;
 }
