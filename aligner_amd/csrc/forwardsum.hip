@@ -47,6 +47,8 @@ constexpr double FS_LN2 = 0.6931471805599453;
 constexpr int FS_RB = 8;                          // frames between re-basings (divides every tile width)
 constexpr int FS_THREADS = 256;                   // wave 0 sweeps, waves 1..3 stage tiles
 constexpr int FS_STAGERS = FS_THREADS - 64;
+constexpr int SY_LD = 68;                         // systolic kernels: floats per frame row of a tile (64 lanes + pad)
+constexpr int SY_NW_MAX = 8;                      // ... offsets in the workspace: one per (wave, frame)
 
 struct FwdSumParams {
     const float *logp;      // [B,Tx,Ty]
@@ -58,6 +60,7 @@ struct FwdSumParams {
     float  *grad;           // [B,Tx,Ty] (backward only)
     int B, Tx, Ty, NT;
     double *doffs;          // workspace [B,SY_NW_MAX,NT]: D_w per (wave, frame) -- the sweeps-side-by-side form only
+    unsigned long long *stamps;   // development (aligner_debug_set_stamps): per (workgroup, wave) 8 words of phase cycle totals
 };
 
 // log2(2^a + 2^b).  The log term is in (0, 1]: its absolute error (~1 ulp of the hardware log2/exp2)
@@ -106,6 +109,151 @@ __device__ __forceinline__ float fs_from_lane_below(float edge, float src) {
 __device__ __forceinline__ float fs_from_lane_above(float edge, float src) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
                                                                  __builtin_bit_cast(int, src), 0x130, 0xf, 0xf, false));
+}
+
+// The stagers' global accesses as raw buffer operations over the utterance's [Tx,Ty] block: the per-lane byte offset of
+// an element (row * Ty + frame-in-tile) never changes, the tile's first frame goes into the SCALAR offset -- no address
+// arithmetic per element and tile.  (Computed per element, it was ~400 VALU issues a phase on the SIMD the sweeper's
+// dependent chain runs on: the phase took 3 300 cycles where the chain needs 1 400.)  Elements that must not be written
+// carry an offset beyond the block: the hardware drops the store.
+constexpr unsigned FS_DROP = 0xFFFFFF00u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fs_rsrc(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (unsigned)(bytes < 0xFFFFFF00ull ? bytes : 0xFFFFFF00ull),
+                                             0x00020000);
+}
+__device__ __forceinline__ float fs_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void fs_bstore(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef ALIGNER_EXP_FS_NOSTORE
+    if (v != 12345.f) return;          // experiment: the sweeps without their tile stores (results are garbage)
+#endif
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// ---- a stager wave of the systolic kernels, with every global access issued by hand ----
+// Measured on the way here (fwdsum at [64,200,1000], 68 phases of ~3 300 cycles): neither the sweepers' instruction
+// count (halved: no change), nor the stagers' address arithmetic (removed: no change), nor their stores (removed: no
+// change) set the phase -- the compiler's waits did: written as loads into arrays, every tile was waited for with
+// vmcnt(15..0), which also waits for every NEWER load, so however many tiles were "in flight" a phase was one memory
+// round trip (~1.4 us through 400 TLB-unfriendly rows).  Here a tile is four (TW = 16) or two 16-byte loads per lane,
+// FS_DEPTH tiles are in flight in FS_DEPTH register sets, and the wait is counted: the order inside a phase is
+// wait - LDS write - stores - loads, so behind a tile's loads there are at least 4 (D - 1) newer operations (the later
+// tiles' loads; stores only add to that) and vmcnt(4 (D - 1)) is always enough, whatever the stores do.
+// Requires T_mel % 4 == 0 and 16-byte aligned tensors (else the callers keep the compiler-scheduled stager).
+typedef unsigned fs_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FS_DEPTH = 4;
+__device__ __forceinline__ void fs_aload4(fs_u32x4 &dst, unsigned voff, const void *sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// (exec = mask for the store only; s_nop: nothing may write the data registers while the store still reads them)
+__device__ __forceinline__ void fs_astore4(unsigned voff, fs_u32x4 data, void *sbase, unsigned long long mask) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 1"
+                 : "=&s"(keep) : "v"(voff), "v"(data), "s"(sbase), "s"(mask) : "memory");
+}
+template <int NJ, int CNT> struct FsWait;
+template <int CNT> struct FsWait<4, CNT> {
+    static __device__ __forceinline__ void on(fs_u32x4 (&q)[4]) {
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "n"(CNT) : "memory");
+    }
+};
+template <int CNT> struct FsWait<2, CNT> {
+    static __device__ __forceinline__ void on(fs_u32x4 (&q)[2]) {
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "n"(CNT) : "memory");
+    }
+};
+
+// in_g / out_g: the utterance's [Tx,Ty] blocks (log-probs in, alpha or beta out); offs_g: this wave's per-frame offsets in
+// the workspace; tin_w / tout_w: this wave's two LDS tiles in / out; toff_w: its two rows of per-frame offsets in LDS.
+// Slot r of the tile is text row 63 w + r - 1 (forward: slot 0 is the ghost of the wave above) or 63 w + r (backward:
+// slot 63 is the ghost of the wave below); `lag`: the phase this wave's first tile is due in.
+template <int SY_TW, bool BACKWARD>
+__device__ __forceinline__ void fs_stager_by_hand(const float *in_g, float *out_g, double *offs_g, float *tin_w, const float *tout_w,
+                                                  const double *toff_w, int lag, int w, int lane, int tx, int ty, int Tx, int Ty,
+                                                  int ntl, int nph, unsigned long long *st = nullptr) {
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, QR = SY_TW / 4, NJ = SY_TW / 4, D = FS_DEPTH;
+    fs_u32x4 q[D][NJ];
+    unsigned vo[NJ], vt[NJ], so[NJ];
+    unsigned long long mfull[NJ], mtail[NJ];
+    int rr[NJ], qd[NJ];
+    bool rowok[NJ];
+    const int tailq = (Ty - (ntl - 1) * SY_TW) / 4;          // quads of the last tile that lie inside the tensor (>= QR: all)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e4 = lane + 64 * j;
+        rr[j] = e4 / QR;
+        qd[j] = e4 - rr[j] * QR;
+        const int rs = BACKWARD ? 63 * w + rr[j] : 63 * w + rr[j] - 1;
+        const int rg = rs < 0 ? 0 : (rs < tx ? rs : tx - 1);
+        const int qc = qd[j] < tailq ? qd[j] : tailq - 1;    // the last tile: quads past the tensor re-read the last one inside
+        vo[j] = (unsigned)(((size_t)rg * Ty + 4 * qd[j]) * sizeof(float));
+        vt[j] = (unsigned)(((size_t)rg * Ty + 4 * qc) * sizeof(float));
+        const bool sv = (BACKWARD ? rr[j] < 63 : rr[j] >= 1) && rs < Tx && rs >= 0;
+        so[j] = (unsigned)(((size_t)(rs < 0 ? 0 : rs) * Ty + 4 * qd[j]) * sizeof(float));
+        mfull[j] = __builtin_amdgcn_ballot_w64(sv);
+        mtail[j] = __builtin_amdgcn_ballot_w64(sv && qd[j] < tailq);
+        rowok[j] = rs < tx;                                   // rows past the text are staged as log 0
+    }
+    auto tile_of = [&](int k) { return BACKWARD ? ntl - 1 - k : k; };          // k-th tile in sweep order
+    auto issue = [&](int k, fs_u32x4 (&s)[NJ]) {
+        const int t = tile_of(k < ntl ? k : ntl - 1);
+        const char *base = reinterpret_cast<const char *>(in_g) + (size_t)t * SY_TW * sizeof(float);
+        const bool last = t == ntl - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fs_aload4(s[j], last ? vt[j] : vo[j], base);
+    };
+    unsigned long long sa[4] = {0, 0, 0, 0};
+    auto phase = [&](int ph, fs_u32x4 (&s)[NJ]) {
+        const int k = ph - lag, ks = ph - 2 - lag;
+        const unsigned long long c0 = st ? __builtin_amdgcn_s_memtime() : 0;
+        FsWait<NJ, NJ * (D - 1)>::on(s);                                       // tile k has landed (see above)
+        const unsigned long long c1 = st ? __builtin_amdgcn_s_memtime() : 0;
+        if (k < ntl) {
+            float *dst = tin_w + (k & 1) * SY_TILE;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float f[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned raw = s[j][jj];        // (bit_cast straight from the vector element reads element 0)
+                    f[jj] = rowok[j] ? fs_in(__builtin_bit_cast(float, raw)) : FS_NEG;
+                }
+                *reinterpret_cast<float4 *>(dst + rr[j] * PITCH + 4 * qd[j]) = make_float4(f[0], f[1], f[2], f[3]);   // one ds_write_b128
+            }
+        }
+        if (ks >= 0 && ks < ntl) {
+            const float *src = tout_w + (ks & 1) * SY_TILE;
+            const int t = tile_of(ks), y0 = t * SY_TW;
+            char *base = reinterpret_cast<char *>(out_g) + (size_t)y0 * sizeof(float);
+            const bool last = t == ntl - 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 f = *reinterpret_cast<const float4 *>(src + rr[j] * PITCH + 4 * qd[j]);       // one ds_read_b128
+                fs_u32x4 d;
+                d[0] = __builtin_bit_cast(unsigned, f.x); d[1] = __builtin_bit_cast(unsigned, f.y);
+                d[2] = __builtin_bit_cast(unsigned, f.z); d[3] = __builtin_bit_cast(unsigned, f.w);
+                fs_astore4(so[j], d, base, last ? mtail[j] : mfull[j]);
+            }
+            if (lane < SY_TW && y0 + lane < ty) offs_g[y0 + lane] = toff_w[(ks & 1) * SY_TW + lane];
+        }
+        unsigned long long c2 = 0;
+        if (st) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = __builtin_amdgcn_s_memtime(); }
+        issue(k + D, s);                                                       // (behind the stores: the wait's count)
+        const unsigned long long c3 = st ? __builtin_amdgcn_s_memtime() : 0;
+        fs_lds_barrier();
+        if (st) { sa[0] += c1 - c0; sa[1] += c2 - c1; sa[2] += c3 - c2; sa[3] += __builtin_amdgcn_s_memtime() - c3; }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, q[d]);
+    for (int ph = 0; ph < lag; ++ph) fs_lds_barrier();                         // (this stager's first tile is due in phase `lag`)
+    for (int ph = lag; ph < nph; ph += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (ph + d < nph) phase(ph + d, q[d]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the loads nobody consumed
+    if (st && lane == 0) { st[0] = sa[0]; st[1] = sa[1]; st[2] = sa[2]; st[3] = sa[3]; st[4] = (unsigned long long)(nph - lag); }
 }
 
 // ---- forward: alpha (frame y relative to C_y), the offsets, log Z, loss ----
@@ -370,18 +518,23 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_backward_kernel(FwdSumParam
 // of that frame and is converted on arrival:  ghost = value + float(C_sender[y] - C_receiver[y]).
 // The workspace holds one offset per (wave, frame); posterior = exp2(alpha + beta + C_w[y] + D_w[y] - log Z).
 // --------------------------------------------------------------------------
-constexpr int SY_LD = 68;                          // floats per frame row of a tile (64 lanes + pad)
-constexpr int SY_NW_MAX = 8;                       // offsets in the workspace: one per (wave, frame)
 // NW sweeping waves (T_text <= 63 NW) and TW frames per tile: <4, 16> up to 252 rows, <8, 8> up to 504 (the
 // 16-wave workgroup has 128 VGPRs per lane and the backward kernel four tile arrays in LDS)
 
 template <int SY_NW, int SY_TW>
 __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, const int b) {
-    constexpr int SY_TILE = SY_TW * SY_LD;
+    // tiles are SLOT-major, a slot's TW frames contiguous and slots TW + 4 floats apart: every wave moves its tile with
+    // 16-byte LDS accesses (a sweeper lane's operands are TW / 4 ds_read_b128, conflict-free at this pitch; frame-major,
+    // they were 2 x TW ds_read_b32 and 850 of a phase's 3 200 cycles: tools/fwdsum_stamps.py)
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    float *tin = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
-    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha
+    float *tin = fs_smem;                                     // [NW][2][64][PITCH] log-probs (slot = lane)
+    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][64][PITCH] alpha
     double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    constexpr int RB = SY_TW, NG = SY_TW / RB;                // frames between re-basings: once per tile (the rebasing
+    // ladder is ~170 cycles of the sweeper's chain; fp32 holds the column near 0 over 16 frames as well as over 8)
+    double *tcg = toff + SY_NW * 2 * SY_TW;                   // [NW][2][NG] C_w at the start of each group ...
+    float *tdr = reinterpret_cast<float *>(tcg + SY_NW * 2 * NG);            // [NW][2][NG] ... and the group's drift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1);
@@ -399,106 +552,187 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
     const int ntl = (ty + SY_TW - 1) / SY_TW;
     const int row = 63 * w + lane - 1;                        // sweeper: lane 0 is the ghost (row 63w-1)
     float prev = (w == 0 && lane == 0) ? 0.f : FS_NEG;        // row -1 is log 1 before the first frame
-    const bool ghost = lane == 0, rowok = row < tx;
+    const bool ghost = lane == 0;
     float drift = 0.f;
-    double C = 0.0, drift_d = 0.0;
     // Two loops, one per role (same phase count): the stagers' tile in flight is then live in their loop only
-    if (!sweeper) {
-        // stagers: the tile of the NEXT phase is already in flight while this phase's tile goes into LDS (loaded and
-        // waited for inside one phase, a tile cost a memory round trip per phase: staging alone took as long as the sweep)
-        float vnext[SY_TW];
-        auto stage_issue = [&](int tl) {                          // unconditional loads (row and frame clamped into the utterance)
+    const bool by_hand = p.Ty % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.alpha)) & 15) == 0 &&
+                         (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
+    if (!sweeper && by_hand) {
+        fs_stager_by_hand<SY_TW, false>(p.logp + ubase, p.alpha + ubase, offs, tin + w * 2 * SY_TILE, tout + w * 2 * SY_TILE,
+                                        toff + w * 2 * SY_TW, w, w, lane, tx, ty, p.Tx, p.Ty, ntl, ntl + SY_NW + 1,
+                                        p.stamps ? p.stamps + ((size_t)b * 16 + wave) * 8 : nullptr);
+    } else if (!sweeper) {
+        // stagers: TWO tiles in flight (even tiles in one register set, odd ones in the other; the phase loop is unrolled
+        // by two so that nothing is copied -- a copy would wait for the newest loads).  With one tile in flight a phase
+        // could not be shorter than a memory round trip, whatever the sweepers did.
+        float vA[SY_TW], vB[SY_TW];
+        const size_t ubytes = (size_t)p.Tx * p.Ty * sizeof(float);
+        const bool fastio = ubytes < 0xFFFFFF00ull;
+        const __amdgpu_buffer_rsrc_t rs_in = fs_rsrc(p.logp + ubase, ubytes), rs_out = fs_rsrc(p.alpha + ubase, ubytes);
+        unsigned vo[SY_TW], so[SY_TW];                        // element offsets inside the block: loads (rows clamped), stores
+#pragma unroll
+        for (int i = 0; i < SY_TW; ++i) {
+            const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+            const int rs = 63 * w + r - 1;
+            const int rg = rs < 0 ? 0 : (rs < tx ? rs : tx - 1);
+            vo[i] = (unsigned)(((size_t)rg * p.Ty + c) * sizeof(float));
+            so[i] = (r >= 1 && rs < p.Tx) ? (unsigned)(((size_t)rs * p.Ty + c) * sizeof(float)) : FS_DROP;
+        }
+        auto stage_issue = [&](int tl, float (&v)[SY_TW]) {      // unconditional loads (row and frame clamped into the utterance)
             const int tc = tl < ntl ? tl : ntl - 1;
             const int y0 = tc * SY_TW;
+            if (fastio && y0 + SY_TW <= p.Ty) {                   // a whole tile inside the tensor: no address arithmetic
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) v[i] = fs_bload(rs_in, vo[i], (unsigned)y0 * 4u);
+                return;
+            }
     #pragma unroll
             for (int i = 0; i < SY_TW; ++i) {
                 const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;     // slot r, frame c
                 int rg = 63 * w + r - 1;
                 rg = rg < 0 ? 0 : (rg < tx ? rg : tx - 1);
                 const int yc = y0 + c < ty ? y0 + c : ty - 1;
-                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
             }
         };
-        stage_issue(0);
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        auto phase = [&](int ph, float (&v)[SY_TW]) {
             const int tl = ph - w, ts = ph - 2 - w;
             if (tl >= 0 && tl < ntl) {
                 float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dst[c * SY_LD + r] = fs_in(vnext[i]);
+                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_in(v[i]) : FS_NEG;   // rows past the text: log 0
                 }
-                stage_issue(tl + 1);
+                stage_issue(tl + 2, v);
             }
             if (ts >= 0 && ts < ntl) {
                 const float *src = tout + (w * 2 + (ts & 1)) * SY_TILE;
                 const int y0 = ts * SY_TW;
+                if (fastio && y0 + SY_TW <= p.Ty) {
 #pragma unroll
-                for (int i = 0; i < SY_TW; ++i) {
-                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    const int rg = 63 * w + r - 1;
-                    if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                    for (int i = 0; i < SY_TW; ++i) {
+                        const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                        fs_bstore(src[r * PITCH + c], rs_out, so[i], (unsigned)y0 * 4u);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SY_TW; ++i) {
+                        const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                        const int rg = 63 * w + r - 1;
+                        if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[r * PITCH + c];
+                    }
                 }
                 if (lane < SY_TW && y0 + lane < ty) offs[y0 + lane] = toff[(w * 2 + (ts & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
+        };
+        stage_issue(0, vA);
+        stage_issue(1, vB);
+        const int nph = ntl + SY_NW + 1;
+        for (int ph = 0; ph < w; ++ph) fs_lds_barrier();          // (this stager's first tile is due in phase w)
+        for (int ph = w; ph < nph; ph += 2) {
+            phase(ph, vA);
+            if (ph + 1 < nph) phase(ph + 1, vB);
         }
     } else {
+        // Per frame the chain is dpp, sub, exp2, add, log2, add (tools/microbench_fwdsum.hip: 75 cycles) and everything
+        // else is kept off it and cheap: no select per row (the stagers wrote log 0 into rows past the text, and log 0
+        // absorbs), no double arithmetic (the offset is linear inside a re-basing group: C(y) = Cg + k * drift, so a
+        // boundary value is converted with one fma from the two waves' (Cg, drift) pairs, published once per group).
+        double Cg = 0.0;                                      // this wave's offset at the start of the current group
+        unsigned long long sa[4] = {0, 0, 0, 0}, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
             const int t = ph - 1 - w;
+            if (p.stamps) c0 = c1 = c2 = c3 = __builtin_amdgcn_s_memtime();
             if (t >= 0 && t < ntl) {
                 const int y0 = t * SY_TW, buf = t & 1;
-                const float *src = tin + (w * 2 + buf) * SY_TILE + lane;
-                float *dst = tout + (w * 2 + buf) * SY_TILE + lane;
+                const float4 *src4 = reinterpret_cast<const float4 *>(tin + (w * 2 + buf) * SY_TILE + lane * PITCH);
+                float4 *dst4 = reinterpret_cast<float4 *>(tout + (w * 2 + buf) * SY_TILE + lane * PITCH);
                 double *myoff = toff + (w * 2 + buf) * SY_TW;
-                // the wave above: its last row's alpha (slot 63) and its offsets of the same frames
-                const float *ring = tout + (((w ? w - 1 : 0) * 2 + buf) * SY_TILE) + 63;
-                const double *cp = toff + ((w ? w - 1 : 0) * 2 + buf) * SY_TW;
-                double Ck = 0.0;                              // lane c keeps C of frame c: one store per tile
-                // the whole tile's operands up front (one LDS latency per tile, not one per frame)
-                float lpv[SY_TW], rgv[SY_TW];
-                double cpv[SY_TW];
+                // the wave above: its last row's alpha (slot 63) and its (Cg, drift) of the same groups
+                const int wu = w ? w - 1 : 0;
+                const float4 *ring4 = reinterpret_cast<const float4 *>(tout + (wu * 2 + buf) * SY_TILE + 63 * PITCH);
+                float lpv[SY_TW], rgv[SY_TW], av[4];
+                double scg[NG], mcg[NG];
+                float sdr[NG], mdr[NG];
 #pragma unroll
-                for (int c = 0; c < SY_TW; ++c) { lpv[c] = src[c * SY_LD]; rgv[c] = ring[c * SY_LD]; cpv[c] = cp[c]; }
+                for (int i = 0; i < SY_TW / 4; ++i) {
+                    const float4 l4 = src4[i], r4 = ring4[i];
+                    lpv[4 * i] = l4.x; lpv[4 * i + 1] = l4.y; lpv[4 * i + 2] = l4.z; lpv[4 * i + 3] = l4.w;
+                    rgv[4 * i] = w ? r4.x : FS_NEG; rgv[4 * i + 1] = w ? r4.y : FS_NEG;
+                    rgv[4 * i + 2] = w ? r4.z : FS_NEG; rgv[4 * i + 3] = w ? r4.w : FS_NEG;
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { scg[g] = tcg[(wu * 2 + buf) * NG + g]; sdr[g] = tdr[(wu * 2 + buf) * NG + g]; }
+                if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
+                    float D0 = 0.f, dl = 0.f;
 #pragma unroll
                     for (int c = 0; c < SY_TW; ++c) {
-                        const int y = y0 + c;
-                        const float lp = lpv[c];
+                        const int y = y0 + c, g = c / RB, k = (c & (RB - 1)) + 1;
+                        if (k == 1) {                                                // a group starts (uniform values)
+                            mcg[g] = Cg;
+                            mdr[g] = drift;
+                            D0 = w ? (float)(scg[g] - Cg) : 0.f;
+                            dl = w ? sdr[g] - drift : 0.f;
+                        }
                         const float up = fs_from_lane_below(FS_NEG, prev);
-                        const float v = fs_lae2(prev, up) + (lp - drift);
-                        C += drift_d;
-                        float a = (rowok && (!TAIL || y < ty)) ? v : FS_NEG;
-                        const float gh = (w != 0) ? fmaxf(rgv[c] + (float)(cpv[c] - C), FS_NEG) : FS_NEG;
-                        a = ghost ? gh : a;
-                        Ck = (lane == c) ? C : Ck;
-                        dst[c * SY_LD] = a;
+                        float m;
+                        asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(prev), "v"(up));
+                        const float base = m + (lpv[c] - drift);
+                        float v = base + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(prev - up)));
+                        if (TAIL && y >= ty) v = FS_NEG;                             // uniform
+                        const float gh = rgv[c] + (D0 + (float)k * dl);              // the sender's value, on this wave's offset
+                        const float a = ghost ? gh : v;
+                        av[c & 3] = a;
+                        if ((c & 3) == 3) dst4[c >> 2] = make_float4(av[0], av[1], av[2], av[3]);
                         prev = a;
                         if (TAIL && y == ty - 1) {                                   // uniform
                             if (row == tx - 1 && !ghost) {
-                                const double lz = (double)a + C;                     // log2 Z
+                                const double lz = (double)a + (Cg + (double)k * (double)drift);   // log2 Z
                                 p.logz[b] = lz;
                                 p.loss[b] = (float)(-lz * FS_LN2);
                             }
                         }
-                        if ((c & (FS_RB - 1)) == FS_RB - 1) {
+                        if (k == RB) {
                             // re-base this wave's running column on its maximum and learn the per-frame drift
-                            float m = fs_wave_max_dpp(prev);
-                            if (m < 0.5f * FS_NEG) m = 0.f;                          // an all-"log 0" column
-                            C += (double)m;
-                            drift += m * (1.0f / FS_RB);
-                            drift_d = (double)drift;
-                            prev = fmaxf(prev - m, FS_NEG);
+                            float mx = fs_wave_max_dpp(prev);
+                            if (mx < 0.5f * FS_NEG) mx = 0.f;                        // an all-"log 0" column
+                            Cg += (double)RB * (double)drift + (double)mx;
+                            drift += mx * (1.0f / RB);
+                            prev = fmaxf(prev - mx, FS_NEG);
                         }
                     }
                 };
                 if (y0 + SY_TW < ty) frames(std::false_type{});
                 else                 frames(std::true_type{});
-                if (lane < SY_TW) myoff[lane] = Ck;
+                if (p.stamps) { asm volatile("" :: "v"(prev)); c2 = __builtin_amdgcn_s_memtime(); }
+                // what the wave below converts with, and the offsets of the tile's frames for the workspace
+                if (lane < NG) {
+                    double cgp = mcg[0];
+                    float drp = mdr[0];
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) { cgp = lane == g ? mcg[g] : cgp; drp = lane == g ? mdr[g] : drp; }
+                    tcg[(w * 2 + buf) * NG + lane] = cgp;
+                    tdr[(w * 2 + buf) * NG + lane] = drp;
+                }
+                if (lane < SY_TW) {
+                    double cgp = mcg[0];
+                    float drp = mdr[0];
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) { cgp = lane / RB == g ? mcg[g] : cgp; drp = lane / RB == g ? mdr[g] : drp; }
+                    myoff[lane] = cgp + (double)((lane & (RB - 1)) + 1) * (double)drp;
+                }
+                if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_amdgcn_s_memtime(); }
             }
             fs_lds_barrier();
+            if (p.stamps) { sa[0] += c1 - c0; sa[1] += c2 - c1; sa[2] += c3 - c2; sa[3] += __builtin_amdgcn_s_memtime() - c3; }
+        }
+        if (p.stamps && lane == 0) {
+            unsigned long long *st = p.stamps + ((size_t)b * 16 + wave) * 8;
+            st[0] = sa[0]; st[1] = sa[1]; st[2] = sa[2]; st[3] = sa[3]; st[4] = (unsigned long long)(ntl + SY_NW + 1);
         }
     }
 }
@@ -514,14 +748,19 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
 // p.grad -- which fwdsum_combine_kernel then turns into the gradient in place.
 template <int SY_NW, int SY_TW, bool BETA_ONLY>
 __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, const int b) {
-    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, SY_THREADS = 2 * SY_NW * 64;   // slot-major tiles (see the forward kernel)
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    float *tlp = fs_smem;                                     // [NW][2][TW][LD] log-probs (slot = lane)
+    float *tlp = fs_smem;                                     // [NW][2][64][PITCH] log-probs (slot = lane)
     float *tal = tlp + SY_NW * 2 * SY_TILE;                   // alpha (relative to C_w)
     float *tgr = tal + SY_NW * 2 * SY_TILE;                   // gradient out
-    float *tg = tgr + SY_NW * 2 * SY_TILE;                    // g = beta + logp (relative to D_w): slot 0 feeds the wave above
-    double *toff = reinterpret_cast<double *>(tg + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
+    float *tg = tgr + SY_NW * 2 * SY_TILE;                    // [NW][2][TW] g = beta + logp (relative to D_w) of a wave's FIRST row: feeds the wave above
+    float *tgd = tg + SY_NW * 2 * SY_TW;                      // [NW][64][4] where the other lanes write theirs
+    double *toff = reinterpret_cast<double *>(tgd + SY_NW * 64 * 4);       // [NW][2][TW] C_w per frame
     double *tdof = toff + SY_NW * 2 * SY_TW;                  // [NW][2][TW] D_w per frame
+    constexpr int RB = SY_TW, NG = SY_TW / RB;                // frames between re-basings: once per tile (the rebasing
+    // ladder is ~170 cycles of the sweeper's chain; fp32 holds the column near 0 over 16 frames as well as over 8)
+    double *tdg = tdof + SY_NW * 2 * SY_TW;                   // [NW][2][NG] D_w at the start of each group ...
+    float *tdr = reinterpret_cast<float *>(tdg + SY_NW * 2 * NG);            // [NW][2][NG] ... and the group's drift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
@@ -543,32 +782,59 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
     double *doffs = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
     float g_prev = FS_NEG;                                    // beta[x,y+1] + logp[x,y+1], relative to D
-    const bool ghost = lane == 63, rowok = row < tx;
+    const bool ghost = lane == 63;
     float drift = 0.f;
-    double D = 0.0, Dl = -logz, drift_d = 0.0;                // Dl = D - log Z
     // Two loops, one per role (the phase count is the same): written as one loop with the role tested inside, the
     // stagers' tile in flight was live through the sweepers' code as well and the kernel spilled (236 -> 493 us).
-    if (!sweeper) {
-        // the NEXT phase's tile (log-probs, alpha, offsets) is in flight while this phase's goes into LDS
-        float vnext[SY_TW], unext[SY_TW];
-        double onext = 0.0;
-        auto stage_issue = [&](int kl) {                      // tile counted from the end, clamped
+    const bool by_hand = BETA_ONLY && p.Ty % 4 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.grad)) & 15) == 0 &&
+                         (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
+    if (!sweeper && by_hand) {
+        fs_stager_by_hand<SY_TW, true>(p.logp + ubase, p.grad + ubase, doffs, tlp + w * 2 * SY_TILE, tgr + w * 2 * SY_TILE,
+                                       tdof + w * 2 * SY_TW, wr, w, lane, tx, ty, p.Tx, p.Ty, ntl, ntl + SY_NW + 1);
+    } else if (!sweeper) {
+        // two tiles (log-probs, alpha, offsets) in flight, as in the forward kernel: even tiles in set A, odd ones in set B
+        struct Set { float v[SY_TW], u[SY_TW]; double o; };
+        Set sA, sB;
+        const size_t ubytes = (size_t)p.Tx * p.Ty * sizeof(float);
+        const bool fastio = ubytes < 0xFFFFFF00ull;
+        const __amdgpu_buffer_rsrc_t rs_in = fs_rsrc(p.logp + ubase, ubytes), rs_al = fs_rsrc(p.alpha + ubase, ubytes),
+                                     rs_out = fs_rsrc(p.grad + ubase, ubytes);
+        unsigned vo[SY_TW], so[SY_TW];                        // element offsets inside the block: loads (rows clamped), stores
+#pragma unroll
+        for (int i = 0; i < SY_TW; ++i) {
+            const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+            const int rs = 63 * w + r;
+            const int rg = rs < tx ? rs : tx - 1;
+            vo[i] = (unsigned)(((size_t)rg * p.Ty + c) * sizeof(float));
+            so[i] = (r < 63 && rs < p.Tx) ? (unsigned)(((size_t)rs * p.Ty + c) * sizeof(float)) : FS_DROP;
+        }
+        auto stage_issue = [&](int kl, Set &q) {              // tile counted from the end, clamped
             const int kc = kl < ntl ? kl : ntl - 1;
             const int y0 = (ntl - 1 - kc) * SY_TW;
+            if (fastio && y0 + SY_TW <= p.Ty) {                   // a whole tile inside the tensor: no address arithmetic
+#pragma unroll
+                for (int i = 0; i < SY_TW; ++i) {
+                    q.v[i] = fs_bload(rs_in, vo[i], (unsigned)y0 * 4u);
+                    if (!BETA_ONLY) q.u[i] = fs_bload(rs_al, vo[i], (unsigned)y0 * 4u);
+                }
+                const int yo = y0 + (lane & (SY_TW - 1));
+                if (!BETA_ONLY) q.o = offs[yo < ty ? yo : ty - 1];
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < SY_TW; ++i) {
                 const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
                 int rg = 63 * w + r;
                 rg = rg < tx ? rg : tx - 1;
                 const int yc = y0 + c < ty ? y0 + c : ty - 1;
-                vnext[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
-                if (!BETA_ONLY) unext[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
+                q.v[i] = p.logp[ubase + (size_t)rg * p.Ty + yc];
+                if (!BETA_ONLY) q.u[i] = p.alpha[ubase + (size_t)rg * p.Ty + yc];
             }
             const int yo = y0 + (lane & (SY_TW - 1));
-            if (!BETA_ONLY) onext = offs[yo < ty ? yo : ty - 1];
+            if (!BETA_ONLY) q.o = offs[yo < ty ? yo : ty - 1];
         };
-        stage_issue(0);
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        auto phase = [&](int ph, Set &q) {
             const int kl = ph - wr, ks = ph - 2 - wr;         // tile counted from the end
             if (kl >= 0 && kl < ntl) {
                 const int t = ntl - 1 - kl, y0 = t * SY_TW;
@@ -576,90 +842,156 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dlp[c * SY_LD + r] = fs_in(vnext[i]);
-                    if (!BETA_ONLY) dal[c * SY_LD + r] = unext[i];
+                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_in(q.v[i]) : FS_NEG;     // rows past the text: log 0
+                    if (!BETA_ONLY) dal[r * PITCH + c] = q.u[i];
                 }
-                if (!BETA_ONLY && lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
-                stage_issue(kl + 1);
+                if (!BETA_ONLY && lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? q.o : 0.0;
+                stage_issue(kl + 2, q);
             }
             if (ks >= 0 && ks < ntl) {
                 const float *src = tgr + (w * 2 + (ks & 1)) * SY_TILE;
                 const int y0 = (ntl - 1 - ks) * SY_TW;
+                if (fastio && y0 + SY_TW <= p.Ty) {
 #pragma unroll
-                for (int i = 0; i < SY_TW; ++i) {
-                    const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    const int rg = 63 * w + r;
-                    if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                    for (int i = 0; i < SY_TW; ++i) {
+                        const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                        fs_bstore(src[r * PITCH + c], rs_out, so[i], (unsigned)y0 * 4u);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < SY_TW; ++i) {
+                        const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
+                        const int rg = 63 * w + r;
+                        if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[r * PITCH + c];
+                    }
                 }
                 if (BETA_ONLY && lane < SY_TW && y0 + lane < ty) doffs[y0 + lane] = tdof[(w * 2 + (ks & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
+        };
+        stage_issue(0, sA);
+        stage_issue(1, sB);
+        const int nph = ntl + SY_NW + 1;
+        for (int ph = 0; ph < wr; ++ph) fs_lds_barrier();         // (this stager's first tile is due in phase wr)
+        for (int ph = wr; ph < nph; ph += 2) {
+            phase(ph, sA);
+            if (ph + 1 < nph) phase(ph + 1, sB);
         }
     } else {
+        // (the frame's work is arranged as in fwdsum_forward_sys_body: no per-row select, offsets linear inside a group)
+        double Dg = 0.0;                                      // this wave's offset at the start of the current group
         for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
-            const int k = ph - 1 - wr;
-            if (k >= 0 && k < ntl) {
-                const int buf = k & 1, y0 = (ntl - 1 - k) * SY_TW;
-                const float *slp = tlp + (w * 2 + buf) * SY_TILE + lane, *sal = tal + (w * 2 + buf) * SY_TILE + lane;
-                float *dgr = tgr + (w * 2 + buf) * SY_TILE + lane, *dg = tg + (w * 2 + buf) * SY_TILE + lane;
+            const int kt = ph - 1 - wr;
+            if (kt >= 0 && kt < ntl) {
+                const int buf = kt & 1, y0 = (ntl - 1 - kt) * SY_TW;
+                const float4 *slp4 = reinterpret_cast<const float4 *>(tlp + (w * 2 + buf) * SY_TILE + lane * PITCH);
+                const float4 *sal4 = reinterpret_cast<const float4 *>(tal + (w * 2 + buf) * SY_TILE + lane * PITCH);
+                float4 *dgr4 = reinterpret_cast<float4 *>(tgr + (w * 2 + buf) * SY_TILE + lane * PITCH);
+                // lane 0's g goes to the ring the wave above reads, everybody else's to a slot of their own
+                float4 *dg4 = reinterpret_cast<float4 *>(lane == 0 ? tg + (w * 2 + buf) * SY_TW : tgd + (w * 64 + lane) * 4);
+                const int dgs = lane == 0 ? 1 : 0;                                  // (quads advance in the ring only)
                 const double *myoff = toff + (w * 2 + buf) * SY_TW;
                 double *mydof = tdof + (w * 2 + buf) * SY_TW;
-                // the wave below: its first row's g (slot 0) and its D offsets of the same frames
-                const int wb = w + 1 < SY_NW ? w + 1 : w;
-                const float *ring = tg + (wb * 2 + buf) * SY_TILE;
-                const double *dp = tdof + (wb * 2 + buf) * SY_TW;
-                double Dk = 0.0;                              // lane c keeps D of frame c
+                // the wave below: its first row's g and its (Dg, drift) of the same groups
+                const bool has = w + 1 < SY_NW;
+                const int wb = has ? w + 1 : w;
+                const float4 *ring4 = reinterpret_cast<const float4 *>(tg + (wb * 2 + buf) * SY_TW);
                 // the whole tile's operands up front (one LDS latency per tile, not one per frame)
-                float lpv[SY_TW], alv[SY_TW], rgv[SY_TW];
-                double cov[SY_TW], dpv[SY_TW];
+                float lpv[SY_TW], alv[SY_TW], rgv[SY_TW], ov[4], gq[4];
+                double cov[SY_TW];
+                double sdg[NG], mdg[NG];
+                float sdr[NG], mdr[NG];
 #pragma unroll
-                for (int c = 0; c < SY_TW; ++c) {
-                    lpv[c] = slp[c * SY_LD]; rgv[c] = ring[c * SY_LD]; dpv[c] = dp[c];
-                    if (!BETA_ONLY) { alv[c] = sal[c * SY_LD]; cov[c] = myoff[c]; }
+                for (int i = 0; i < SY_TW / 4; ++i) {
+                    const float4 l4 = slp4[i], r4 = ring4[i];
+                    lpv[4 * i] = l4.x; lpv[4 * i + 1] = l4.y; lpv[4 * i + 2] = l4.z; lpv[4 * i + 3] = l4.w;
+                    rgv[4 * i] = has ? r4.x : FS_NEG; rgv[4 * i + 1] = has ? r4.y : FS_NEG;
+                    rgv[4 * i + 2] = has ? r4.z : FS_NEG; rgv[4 * i + 3] = has ? r4.w : FS_NEG;
+                    if (!BETA_ONLY) {
+                        const float4 a4 = sal4[i];
+                        alv[4 * i] = a4.x; alv[4 * i + 1] = a4.y; alv[4 * i + 2] = a4.z; alv[4 * i + 3] = a4.w;
+                    }
                 }
+                if (!BETA_ONLY) {
+#pragma unroll
+                    for (int c = 0; c < SY_TW; ++c) cov[c] = myoff[c];
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) { sdg[g] = tdg[(wb * 2 + buf) * NG + g]; sdr[g] = tdr[(wb * 2 + buf) * NG + g]; }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
+                    float D0 = 0.f, dl = 0.f;
+                    double Dlz = 0.0;
 #pragma unroll
                     for (int c = SY_TW - 1; c >= 0; --c) {
-                        const int y = y0 + c;
-                        if (TAIL && y >= ty) {                                       // uniform: padding frames
-                            dgr[c * SY_LD] = 0.f;
+                        const int y = y0 + c, g = c / RB, k = RB - (c & (RB - 1));   // k-th frame of its group
+                        if (k == 1) {                                                // a group starts (uniform values)
+                            mdg[g] = Dg;
+                            mdr[g] = drift;
+                            D0 = has ? (float)(sdg[g] - Dg) : 0.f;
+                            dl = has ? sdr[g] - drift : 0.f;
+                            Dlz = Dg - logz;
+                        }
+                        if (TAIL && y >= ty) {                                       // uniform: padding frames (the state is all
+                            ov[c & 3] = 0.f;                                         // log 0 and the drift 0: nothing moves)
+                            gq[c & 3] = FS_NEG;
+                            if ((c & 3) == 0) {
+                                dgr4[c >> 2] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                                dg4[dgs * (c >> 2)] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                            }
                             continue;
                         }
-                        const float lp = lpv[c];
                         const float dn = fs_from_lane_above(FS_NEG, g_prev);          // row below
                         float beta;
-                        if (TAIL && y == ty - 1) beta = (row == tx - 1) ? 0.f : FS_NEG;   // uniform branch
-                        else                     beta = fs_lae2(g_prev, dn);
-                        beta = rowok ? beta : FS_NEG;
-                        if (BETA_ONLY) {
-                            dgr[c * SY_LD] = beta - drift;            // relative to the D recorded for this frame (D + drift)
+                        if (TAIL && y == ty - 1) {                                   // uniform branch
+                            beta = (row == tx - 1) ? 0.f : FS_NEG;
                         } else {
-                            const float st = (float)(cov[c] + Dl);                   // C_w[y] + D_w - log Z, uniform
-                            dgr[c * SY_LD] = -__builtin_amdgcn_exp2f(alv[c] + beta + st);   // 2^(-1e30) = 0
+                            float m;
+                            asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(g_prev), "v"(dn));
+                            beta = m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(g_prev - dn)));
                         }
-                        float g = fmaxf(beta + (lp - drift), FS_NEG);
-                        D += drift_d;
-                        Dl += drift_d;
-                        const float gh = (w + 1 < SY_NW) ? fmaxf(rgv[c] + (float)(dpv[c] - D), FS_NEG) : FS_NEG;
-                        g = ghost ? gh : g;
-                        dg[c * SY_LD] = g;
-                        Dk = (lane == c) ? D : Dk;
-                        g_prev = g;
-                        if ((c & (FS_RB - 1)) == 0) {
-                            float m = fs_wave_max_dpp(g_prev);
-                            if (m < 0.5f * FS_NEG) m = 0.f;
-                            D += (double)m;
-                            Dl += (double)m;
-                            drift += m * (1.0f / FS_RB);
-                            drift_d = (double)drift;
-                            g_prev = fmaxf(g_prev - m, FS_NEG);
+                        if (BETA_ONLY) {
+                            ov[c & 3] = beta - drift;                 // relative to the D of this frame (Dg + k * drift)
+                        } else {
+                            // C_w[y] + D_w - log Z with D_w = Dg + (k - 1) * drift: the offset beta is relative to
+                            const float st = (float)(cov[c] + Dlz) + (float)(k - 1) * drift;
+                            ov[c & 3] = -__builtin_amdgcn_exp2f(alv[c] + beta + st);        // 2^(-1e30) = 0
+                        }
+                        const float gv = beta + (lpv[c] - drift);
+                        const float gh = rgv[c] + (D0 + (float)k * dl);              // the sender's value, on this wave's offset
+                        const float gn = ghost ? gh : gv;
+                        gq[c & 3] = gn;
+                        if ((c & 3) == 0) {                                          // a quad of frames is complete (c runs down)
+                            dgr4[c >> 2] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                            dg4[dgs * (c >> 2)] = make_float4(gq[0], gq[1], gq[2], gq[3]);
+                        }
+                        g_prev = gn;
+                        if (k == RB) {
+                            float mx = fs_wave_max_dpp(g_prev);
+                            if (mx < 0.5f * FS_NEG) mx = 0.f;
+                            Dg += (double)RB * (double)drift + (double)mx;
+                            drift += mx * (1.0f / RB);
+                            g_prev = fmaxf(g_prev - mx, FS_NEG);
                         }
                     }
                 };
-                if (k != 0) frames(std::false_type{});
-                else        frames(std::true_type{});
-                if (lane < SY_TW) mydof[lane] = Dk;
+                if (kt != 0) frames(std::false_type{});
+                else         frames(std::true_type{});
+                if (lane < NG) {
+                    double dgp = mdg[0];
+                    float drp = mdr[0];
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) { dgp = lane == g ? mdg[g] : dgp; drp = lane == g ? mdr[g] : drp; }
+                    tdg[(w * 2 + buf) * NG + lane] = dgp;
+                    tdr[(w * 2 + buf) * NG + lane] = drp;
+                }
+                if (lane < SY_TW) {                                                  // D of the tile's frames (BETA_ONLY: to the workspace)
+                    double dgp = mdg[0];
+                    float drp = mdr[0];
+#pragma unroll
+                    for (int g = 1; g < NG; ++g) { dgp = lane / RB == g ? mdg[g] : dgp; drp = lane / RB == g ? mdr[g] : drp; }
+                    mydof[lane] = dgp + (double)(RB - (lane & (RB - 1))) * (double)drp;
+                }
             }
             fs_lds_barrier();
         }
@@ -1462,9 +1794,12 @@ static bool fs_side_by_side(int B) { return 8 * B <= 3 * device_cu_count(); }
 
 template <int SY_NW, int SY_TW>
 static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
-    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
-    const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double);
-    const size_t lds_b = (size_t)4 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double);
+    constexpr int SY_THREADS = 2 * SY_NW * 64;
+    constexpr size_t grp = (size_t)SY_NW * 2 * (SY_TW / FS_RB) * (sizeof(double) + sizeof(float));   // (offset, drift) per group
+    constexpr size_t tile = (size_t)64 * (SY_TW + 4) * sizeof(float);                                // slot-major, pitch TW + 4
+    const size_t lds_f = 2 * SY_NW * 2 * tile + (size_t)SY_NW * 2 * SY_TW * sizeof(double) + grp;
+    const size_t lds_b = 3 * SY_NW * 2 * tile + (size_t)SY_NW * (2 * SY_TW + 64 * 4) * sizeof(float) +
+                         (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) + grp;
     auto kf = fwdsum_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_backward_sys_kernel<SY_NW, SY_TW>;
     // with the gradient, on a batch that leaves half the CUs idle: both sweeps in one launch, then the combining pass
@@ -1563,7 +1898,7 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     FwdSumParams p{logp, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off),
                    reinterpret_cast<double *>(ws + L.offs_off), reinterpret_cast<double *>(ws + L.logz_off),
-                   loss_out, grad_out, B, Tx, Ty, L.NT, reinterpret_cast<double *>(ws + L.doffs_off)};
+                   loss_out, grad_out, B, Tx, Ty, L.NT, reinterpret_cast<double *>(ws + L.doffs_off), g_debug_stamps};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
     if (!g_opt_fwdsum_one_wave) {
