@@ -47,7 +47,6 @@ constexpr double FS_LN2 = 0.6931471805599453;
 constexpr int FS_RB = 8;                          // frames between re-basings (divides every tile width)
 constexpr int FS_THREADS = 256;                   // wave 0 sweeps, waves 1..3 stage tiles
 constexpr int FS_STAGERS = FS_THREADS - 64;
-constexpr int SY_LD = 68;                         // systolic kernels: floats per frame row of a tile (64 lanes + pad)
 constexpr int SY_NW_MAX = 8;                      // ... offsets in the workspace: one per (wave, frame)
 
 struct FwdSumParams {
@@ -1385,12 +1384,16 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_ctc_backward_kernel(CtcPara
 template <int SY_NW, int SY_TW>
 __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, const int b) {
     const FwdSumParams &p = q.f;
-    constexpr int SY_TILE = SY_TW * SY_LD;
+    // (tiles slot-major at a pitch of TW + 4 floats, stagers issued by hand, one re-basing per tile, offsets linear inside
+    // it: everything fwdsum_forward_sys_body says; what differs is the frame's arithmetic)
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, RB = SY_TW;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    float *tin = fs_smem;                                     // [NW][2][TW][LD] scores (slot = lane)
-    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][TW][LD] alpha of the token states
+    float *tin = fs_smem;                                     // [NW][2][64][PITCH] scores (slot = lane)
+    float *tout = tin + SY_NW * 2 * SY_TILE;                  // [NW][2][64][PITCH] alpha of the token states
     double *toff = reinterpret_cast<double *>(tout + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
-    double *tns = toff + SY_NW * 2 * SY_TW;                   // [TW] partial sums of the frames' normalisers
+    double *tcg = toff + SY_NW * 2 * SY_TW;                   // [NW][2] C_w at the start of the tile ...
+    double *tns = tcg + SY_NW * 2;                            // [64] partial sums of the frames' normalisers
+    float *tdr = reinterpret_cast<float *>(tns + 64);         // [NW][2] ... and the tile's drift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1);
@@ -1405,15 +1408,24 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
         if (!sweeper) for (int t = lane; t < p.NT; t += 64) offs[t] = 0.0;
         return;
     }
-    const int ntl = (ty + SY_TW - 1) / SY_TW;
+    const int ntl = (ty + SY_TW - 1) / SY_TW, nph = ntl + SY_NW + 1;
     const int row = 63 * w + lane - 1;                        // sweeper: lane 0 is the ghost (row 63w-1)
-    const bool ghost = lane == 0, okT = row < tx, okB = row <= tx;
-    float pT = FS_NEG, pB = (row == 0) ? 0.f : FS_NEG;        // B_0 before the first frame: log 1
-    float drift = 0.f;
-    double C = 0.0, drift_d = 0.0;
+    const bool ghost = lane == 0;
     if (!sweeper) {
+        if (w == 0) {                                         // the normalisers' sum, 64 partial sums (read in the last phase)
+            double ns = 0.0;
+            for (int y = lane; y < ty; y += 64) ns += (double)q.nrm[(size_t)b * p.Ty + y];
+            tns[lane] = ns;
+        }
+        const bool by_hand = p.Ty % 4 == 0 && ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.alpha)) & 15) == 0 &&
+                             (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
+        if (by_hand) {
+            fs_stager_by_hand<SY_TW, false>(p.logp + ubase, p.alpha + ubase, offs, tin + w * 2 * SY_TILE, tout + w * 2 * SY_TILE,
+                                            toff + w * 2 * SY_TW, w, w, lane, tx, ty, p.Tx, p.Ty, ntl, nph);
+            return;
+        }
+        // any T_mel / alignment: one tile in flight, scheduled by the compiler (a phase is then a memory round trip)
         float vnext[SY_TW];
-        double nsd = 0.0;                                     // stager 0, lane c: the normalisers of the frames = c mod TW
         auto stage_issue = [&](int tl) {
             const int tc = tl < ntl ? tl : ntl - 1;
             const int y0 = tc * SY_TW;
@@ -1427,19 +1439,14 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
             }
         };
         stage_issue(0);
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        for (int ph = 0; ph < nph; ++ph) {
             const int tl = ph - w, ts = ph - 2 - w;
             if (tl >= 0 && tl < ntl) {
                 float *dst = tin + (w * 2 + (tl & 1)) * SY_TILE;
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dst[c * SY_LD + r] = fs_in(vnext[i]);
-                }
-                if (w == 0 && lane < SY_TW) {
-                    const int y = tl * SY_TW + lane;
-                    if (y < ty) nsd += (double)q.nrm[(size_t)b * p.Ty + y];
-                    if (tl == ntl - 1) tns[lane] = nsd;       // (read by the last frame's sweeper, phases later)
+                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_in(vnext[i]) : FS_NEG;   // rows past the text: log 0
                 }
                 stage_issue(tl + 1);
             }
@@ -1450,73 +1457,86 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
                     const int rg = 63 * w + r - 1;
-                    if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                    if (r >= 1 && rg < p.Tx && y0 + c < p.Ty) p.alpha[ubase + (size_t)rg * p.Ty + y0 + c] = src[r * PITCH + c];
                 }
                 if (lane < SY_TW && y0 + lane < ty) offs[y0 + lane] = toff[(w * 2 + (ts & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
         }
-    } else {
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
-            const int t = ph - 1 - w;
-            if (t >= 0 && t < ntl) {
-                const int y0 = t * SY_TW, buf = t & 1;
-                const float *src = tin + (w * 2 + buf) * SY_TILE + lane;
-                float *dst = tout + (w * 2 + buf) * SY_TILE + lane;
-                double *myoff = toff + (w * 2 + buf) * SY_TW;
-                const float *ring = tout + (((w ? w - 1 : 0) * 2 + buf) * SY_TILE) + 63;   // the wave above: its last row's token state
-                const double *cp = toff + ((w ? w - 1 : 0) * 2 + buf) * SY_TW;
-                double Ck = 0.0;
-                float xv[SY_TW], rgv[SY_TW];
-                double cpv[SY_TW];
+        return;
+    }
+    // ---- sweepers.  A frame: L = lse(B, T of the row above) serves both states --
+    //     B' = blank + L,   T' = x + lse(T, L)
+    // four transcendentals where the two independent sums took six.  No select per row: rows past the text were staged as
+    // log 0 (the token state dies there), and a blank state is alive exactly where its inputs are (row t_x: from the last
+    // token; below it nothing is).
+    float pT = FS_NEG, pB = (row == 0) ? 0.f : FS_NEG;        // B_0 before the first frame: log 1
+    float drift = 0.f;
+    double Cg = 0.0;
+    for (int ph = 0; ph < nph; ++ph) {
+        const int t = ph - 1 - w;
+        if (t >= 0 && t < ntl) {
+            const int y0 = t * SY_TW, buf = t & 1;
+            const float4 *src4 = reinterpret_cast<const float4 *>(tin + (w * 2 + buf) * SY_TILE + lane * PITCH);
+            float4 *dst4 = reinterpret_cast<float4 *>(tout + (w * 2 + buf) * SY_TILE + lane * PITCH);
+            const int wu = w ? w - 1 : 0;                     // the wave above: its last row's token state, its (Cg, drift)
+            const float4 *ring4 = reinterpret_cast<const float4 *>(tout + (wu * 2 + buf) * SY_TILE + 63 * PITCH);
+            float xv[SY_TW], rgv[SY_TW], av[4];
 #pragma unroll
-                for (int c = 0; c < SY_TW; ++c) { xv[c] = src[c * SY_LD]; rgv[c] = ring[c * SY_LD]; cpv[c] = cp[c]; }
-                auto frames = [&](auto tail) {
-                    constexpr bool TAIL = decltype(tail)::value;
+            for (int i = 0; i < SY_TW / 4; ++i) {
+                const float4 l4 = src4[i], r4 = ring4[i];
+                xv[4 * i] = l4.x; xv[4 * i + 1] = l4.y; xv[4 * i + 2] = l4.z; xv[4 * i + 3] = l4.w;
+                rgv[4 * i] = w ? r4.x : FS_NEG; rgv[4 * i + 1] = w ? r4.y : FS_NEG;
+                rgv[4 * i + 2] = w ? r4.z : FS_NEG; rgv[4 * i + 3] = w ? r4.w : FS_NEG;
+            }
+            const double scg = tcg[wu * 2 + buf];
+            const float sdr = tdr[wu * 2 + buf];
+            const double mcg = Cg;
+            const float mdr = drift;
+            const float D0 = w ? (float)(scg - Cg) : 0.f, dl = w ? sdr - drift : 0.f;
+            const float bl = q.blank2 - drift;
+            auto frames = [&](auto tail) {
+                constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
-                    for (int c = 0; c < SY_TW; ++c) {
-                        const int y = y0 + c;
-                        const float upT = fs_from_lane_below(FS_NEG, pT);
-                        const float vb = fs_lae2(pB, upT) + (q.blank2 - drift);
-                        const float vt = fs_lae3(pT, pB, upT) + (xv[c] - drift);
-                        C += drift_d;
-                        const bool in = !TAIL || y < ty;
-                        float nB = (okB && in) ? fmaxf(vb, FS_NEG) : FS_NEG;
-                        float nT = (okT && in) ? fmaxf(vt, FS_NEG) : FS_NEG;
-                        const float gh = (w != 0) ? fmaxf(rgv[c] + (float)(cpv[c] - C), FS_NEG) : FS_NEG;
-                        nT = ghost ? gh : nT;
-                        nB = ghost ? FS_NEG : nB;
-                        Ck = (lane == c) ? C : Ck;
-                        dst[c * SY_LD] = nT;
-                        pT = nT;
-                        pB = nB;
-                        if (TAIL && y == ty - 1) {                                   // uniform: Z = T_{tx-1} + B_tx
-                            const float below = fs_from_lane_below(FS_NEG, pT);
-                            if (row == tx && !ghost) {
-                                double ns = 0.0;
-                                for (int k = 0; k < SY_TW; ++k) ns += tns[k];
-                                const double lz = (double)fs_lae2(pB, below) + C;    // log2 Z of the raw scores
-                                p.logz[b] = lz;
-                                p.loss[b] = (float)(-(lz - ns) * FS_LN2);
-                            }
-                        }
-                        if ((c & (FS_RB - 1)) == FS_RB - 1) {
-                            float m = fs_wave_max_dpp(fmaxf(pT, pB));
-                            if (m < 0.5f * FS_NEG) m = 0.f;
-                            C += (double)m;
-                            drift += m * (1.0f / FS_RB);
-                            drift_d = (double)drift;
-                            pT = fmaxf(pT - m, FS_NEG);
-                            pB = fmaxf(pB - m, FS_NEG);
+                for (int c = 0; c < SY_TW; ++c) {
+                    const int y = y0 + c, k = c + 1;
+                    const float upT = fs_from_lane_below(FS_NEG, pT);
+                    const float L = fs_lae2(pB, upT);
+                    float vb = L + bl;
+                    float vt = fs_lae2(pT, L) + (xv[c] - drift);
+                    if (TAIL && y >= ty) { vb = FS_NEG; vt = FS_NEG; }                  // uniform
+                    const float gh = rgv[c] + (D0 + (float)k * dl);                    // the sender's value, on this wave's offset
+                    const float nT = ghost ? gh : vt;
+                    pB = ghost ? FS_NEG : vb;
+                    pT = nT;
+                    av[c & 3] = nT;
+                    if ((c & 3) == 3) dst4[c >> 2] = make_float4(av[0], av[1], av[2], av[3]);
+                    if (TAIL && y == ty - 1) {                                           // uniform: Z = T_{tx-1} + B_tx
+                        const float below = fs_from_lane_below(FS_NEG, pT);
+                        if (row == tx && !ghost) {
+                            double ns = 0.0;
+                            for (int j = 0; j < 64; ++j) ns += tns[j];
+                            const double lz = (double)fs_lae2(pB, below) + (Cg + (double)k * (double)drift);   // log2 Z of the raw scores
+                            p.logz[b] = lz;
+                            p.loss[b] = (float)(-(lz - ns) * FS_LN2);
                         }
                     }
-                };
-                if (y0 + SY_TW < ty) frames(std::false_type{});
-                else                 frames(std::true_type{});
-                if (lane < SY_TW) myoff[lane] = Ck;
+                }
+            };
+            if (y0 + SY_TW < ty) frames(std::false_type{});
+            else                 frames(std::true_type{});
+            {   // re-base on the column's maximum, learn the per-frame drift
+                float mx = fs_wave_max_dpp(fmaxf(pT, pB));
+                if (mx < 0.5f * FS_NEG) mx = 0.f;
+                Cg += (double)RB * (double)drift + (double)mx;
+                drift += mx * (1.0f / RB);
+                pT = fmaxf(pT - mx, FS_NEG);
+                pB = fmaxf(pB - mx, FS_NEG);
             }
-            fs_lds_barrier();
+            if (lane == 0) { tcg[w * 2 + buf] = mcg; tdr[w * 2 + buf] = mdr; }
+            if (lane < SY_TW) toff[(w * 2 + buf) * SY_TW + lane] = mcg + (double)(lane + 1) * (double)mdr;
         }
+        fs_lds_barrier();
     }
 }
 
@@ -1530,16 +1550,18 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(
 template <int SY_NW, int SY_TW, bool BETA_ONLY>
 __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q, const int b) {
     const FwdSumParams &p = q.f;
-    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, SY_THREADS = 2 * SY_NW * 64, RB = SY_TW;
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
-    float *tlp = fs_smem;                                     // [NW][2][TW][LD] scores (slot = lane)
+    float *tlp = fs_smem;                                     // [NW][2][64][PITCH] scores (slot = lane)
     float *tal = tlp + SY_NW * 2 * SY_TILE;                   // alpha of the token states (relative to C_w)
     float *tgr = tal + SY_NW * 2 * SY_TILE;                   // gradient out
     double *toff = reinterpret_cast<double *>(tgr + SY_NW * 2 * SY_TILE);   // [NW][2][TW] C_w per frame
     double *tdof = toff + SY_NW * 2 * SY_TW;                  // [NW][2][TW] D_w per frame
-    float2 *tg = reinterpret_cast<float2 *>(tdof + SY_NW * 2 * SY_TW);     // [NW][2][TW] (g_B, g_T) of a wave's FIRST row
-    float *tnrm = reinterpret_cast<float *>(tg + SY_NW * 2 * SY_TW);       // [NW][2][TW] n_y
-    float2 *dump = reinterpret_cast<float2 *>(tnrm + SY_NW * 2 * SY_TW);   // [NW][64] where the other lanes write
+    double *tdg = tdof + SY_NW * 2 * SY_TW;                   // [NW][2] D_w at the start of the tile ...
+    float2 *tg = reinterpret_cast<float2 *>(tdg + SY_NW * 2); // [NW][2][TW] (g_B, g_T) of a wave's FIRST row
+    float2 *dump = tg + SY_NW * 2 * SY_TW;                    // [NW][64] where the other lanes write
+    float *tnrm = reinterpret_cast<float *>(dump + SY_NW * 64);            // [NW][2][TW] n_y
+    float *tdr = tnrm + SY_NW * 2 * SY_TW;                    // [NW][2] ... and the tile's drift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = wave & (SY_NW - 1), wr = SY_NW - 1 - w;     // wave SY_NW-1 (the last rows) leads
@@ -1549,7 +1571,7 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
     ty = ty > p.Ty ? p.Ty : ty;
     const bool ok = tx >= 1 && tx <= ty;
     const size_t ubase = (size_t)b * p.Tx * p.Ty;
-    const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0;
+    const int ntl = ok ? (ty + SY_TW - 1) / SY_TW : 0, nph = ntl + SY_NW + 1;
     if (!BETA_ONLY)
         for (int r = 0; r < p.Tx; ++r)
             for (int y = ntl * SY_TW + tid; y < p.Ty; y += SY_THREADS) p.grad[ubase + (size_t)r * p.Ty + y] = 0.f;
@@ -1558,11 +1580,16 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
     const double *offs = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     double *doffs = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT;
     const int row = 63 * w + lane;                            // sweeper: lane 63 is the ghost (row 63w+63)
-    float gT = FS_NEG, gB = FS_NEG;                           // beta + emission of frame y+1, relative to D
-    const bool ghost = lane == 63, okT = row < tx, okB = row <= tx;
-    float drift = 0.f;
-    double D = 0.0, Dl = -logz, drift_d = 0.0;                // Dl = D - log Z
+    const bool ghost = lane == 63;
     if (!sweeper) {
+        const bool by_hand = BETA_ONLY && p.Ty % 4 == 0 &&
+                             ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.grad)) & 15) == 0 &&
+                             (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
+        if (by_hand) {
+            fs_stager_by_hand<SY_TW, true>(p.logp + ubase, p.grad + ubase, doffs, tlp + w * 2 * SY_TILE, tgr + w * 2 * SY_TILE,
+                                           tdof + w * 2 * SY_TW, wr, w, lane, tx, ty, p.Tx, p.Ty, ntl, nph);
+            return;
+        }
         float vnext[SY_TW], unext[SY_TW];
         double onext = 0.0;
         float nnext = 0.f;
@@ -1585,7 +1612,7 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
             }
         };
         stage_issue(0);
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
+        for (int ph = 0; ph < nph; ++ph) {
             const int kl = ph - wr, ks = ph - 2 - wr;         // tile counted from the end
             if (kl >= 0 && kl < ntl) {
                 const int t = ntl - 1 - kl, y0 = t * SY_TW;
@@ -1593,8 +1620,8 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dlp[c * SY_LD + r] = fs_in(vnext[i]);
-                    if (!BETA_ONLY) dal[c * SY_LD + r] = unext[i];
+                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_in(vnext[i]) : FS_NEG;   // rows past the text: log 0
+                    if (!BETA_ONLY) dal[r * PITCH + c] = unext[i];
                 }
                 if (!BETA_ONLY && lane < SY_TW) {
                     toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? onext : 0.0;
@@ -1609,95 +1636,109 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
                     const int rg = 63 * w + r;
-                    if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[c * SY_LD + r];
+                    if (r < 63 && rg < p.Tx && y0 + c < p.Ty) p.grad[ubase + (size_t)rg * p.Ty + y0 + c] = src[r * PITCH + c];
                 }
                 if (BETA_ONLY && lane < SY_TW && y0 + lane < ty) doffs[y0 + lane] = tdof[(w * 2 + (ks & 1)) * SY_TW + lane];
             }
             fs_lds_barrier();
         }
-    } else {
-        for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
-            const int k = ph - 1 - wr;
-            if (k >= 0 && k < ntl) {
-                const int buf = k & 1, y0 = (ntl - 1 - k) * SY_TW;
-                const float *slp = tlp + (w * 2 + buf) * SY_TILE + lane, *sal = tal + (w * 2 + buf) * SY_TILE + lane;
-                float *dgr = tgr + (w * 2 + buf) * SY_TILE + lane;
-                const double *myoff = toff + (w * 2 + buf) * SY_TW;
-                const float *mynrm = tnrm + (w * 2 + buf) * SY_TW;
-                double *mydof = tdof + (w * 2 + buf) * SY_TW;
-                float2 *myg = tg + (w * 2 + buf) * SY_TW;
-                float2 *mydump = dump + w * 64 + lane;
-                const int wb = w + 1 < SY_NW ? w + 1 : w;     // the wave below: its first row's states, its D offsets
-                const float2 *ring = tg + (wb * 2 + buf) * SY_TW;
-                const double *dp = tdof + (wb * 2 + buf) * SY_TW;
-                double Dk = 0.0;
-                float xv[SY_TW], alv[SY_TW], nyv[SY_TW];
-                float2 rgv[SY_TW];
-                double cov[SY_TW], dpv[SY_TW];
+        return;
+    }
+    // ---- sweepers (no select per row: see the forward kernel; below row t_x every state stays log 0 by itself) ----
+    float gT = FS_NEG, gB = FS_NEG;                           // beta + emission of frame y+1, relative to D
+    float drift = 0.f;
+    double Dg = 0.0;
+    for (int ph = 0; ph < nph; ++ph) {
+        const int kt = ph - 1 - wr;
+        if (kt >= 0 && kt < ntl) {
+            const int buf = kt & 1, y0 = (ntl - 1 - kt) * SY_TW;
+            const float4 *slp4 = reinterpret_cast<const float4 *>(tlp + (w * 2 + buf) * SY_TILE + lane * PITCH);
+            const float4 *sal4 = reinterpret_cast<const float4 *>(tal + (w * 2 + buf) * SY_TILE + lane * PITCH);
+            float4 *dgr4 = reinterpret_cast<float4 *>(tgr + (w * 2 + buf) * SY_TILE + lane * PITCH);
+            const double *myoff = toff + (w * 2 + buf) * SY_TW;
+            const float *mynrm = tnrm + (w * 2 + buf) * SY_TW;
+            float2 *myg = (lane == 0) ? tg + (w * 2 + buf) * SY_TW : dump + w * 64 + lane;
+            const int mgs = lane == 0 ? 1 : 0;                // (frames advance in the ring only)
+            const bool has = w + 1 < SY_NW;
+            const int wb = has ? w + 1 : w;                   // the wave below: its first row's states, its (Dg, drift)
+            const float2 *ring = tg + (wb * 2 + buf) * SY_TW;
+            float xv[SY_TW], alv[SY_TW], nyv[SY_TW], ov[4];
+            float2 rgv[SY_TW];
+            double cov[SY_TW];
 #pragma unroll
-                for (int c = 0; c < SY_TW; ++c) {
-                    xv[c] = slp[c * SY_LD]; rgv[c] = ring[c]; dpv[c] = dp[c];
-                    if (!BETA_ONLY) { alv[c] = sal[c * SY_LD]; cov[c] = myoff[c]; nyv[c] = mynrm[c]; }
+            for (int i = 0; i < SY_TW / 4; ++i) {
+                const float4 l4 = slp4[i];
+                xv[4 * i] = l4.x; xv[4 * i + 1] = l4.y; xv[4 * i + 2] = l4.z; xv[4 * i + 3] = l4.w;
+                if (!BETA_ONLY) {
+                    const float4 a4 = sal4[i];
+                    alv[4 * i] = a4.x; alv[4 * i + 1] = a4.y; alv[4 * i + 2] = a4.z; alv[4 * i + 3] = a4.w;
                 }
-                auto frames = [&](auto tail) {
-                    constexpr bool TAIL = decltype(tail)::value;
-#pragma unroll
-                    for (int c = SY_TW - 1; c >= 0; --c) {
-                        const int y = y0 + c;
-                        if (TAIL && y >= ty) {                                       // uniform: padding frames
-                            dgr[c * SY_LD] = 0.f;
-                            continue;
-                        }
-                        const float x = xv[c];
-                        const float aB = fs_from_lane_above(FS_NEG, gB);             // the row below
-                        const float aT = fs_from_lane_above(FS_NEG, gT);
-                        float bT, bB;
-                        if (TAIL && y == ty - 1) {                                   // uniform branch
-                            bT = (row == tx - 1) ? 0.f : FS_NEG;
-                            bB = (row == tx) ? 0.f : FS_NEG;
-                        } else {
-                            bT = fs_lae3(gT, aB, aT);
-                            bB = fs_lae2(gB, gT);
-                        }
-                        bT = okT ? bT : FS_NEG;
-                        bB = okB ? bB : FS_NEG;
-                        if (BETA_ONLY) {
-                            dgr[c * SY_LD] = bT - drift;              // relative to the D recorded for this frame (D + drift)
-                        } else {
-                            const float st = (float)(cov[c] + Dl);                   // C_w[y] + D_w - log Z, uniform
-                            const float occ = __builtin_amdgcn_exp2f(alv[c] + bT + st);   // 2^(-1e30) = 0
-                            dgr[c * SY_LD] = okT ? __builtin_amdgcn_exp2f(x - nyv[c]) - occ : 0.f;
-                        }
-                        float nT = fmaxf(bT + (x - drift), FS_NEG);
-                        float nB = fmaxf(bB + (q.blank2 - drift), FS_NEG);
-                        D += drift_d;
-                        Dl += drift_d;
-                        const float cv = (float)(dpv[c] - D);
-                        const bool has = w + 1 < SY_NW;
-                        nT = ghost ? (has ? fmaxf(rgv[c].y + cv, FS_NEG) : FS_NEG) : nT;
-                        nB = ghost ? (has ? fmaxf(rgv[c].x + cv, FS_NEG) : FS_NEG) : nB;
-                        *((lane == 0) ? myg + c : mydump) = make_float2(nB, nT);
-                        Dk = (lane == c) ? D : Dk;
-                        gT = nT;
-                        gB = nB;
-                        if ((c & (FS_RB - 1)) == 0) {
-                            float m = fs_wave_max_dpp(fmaxf(gT, gB));
-                            if (m < 0.5f * FS_NEG) m = 0.f;
-                            D += (double)m;
-                            Dl += (double)m;
-                            drift += m * (1.0f / FS_RB);
-                            drift_d = (double)drift;
-                            gT = fmaxf(gT - m, FS_NEG);
-                            gB = fmaxf(gB - m, FS_NEG);
-                        }
-                    }
-                };
-                if (k != 0) frames(std::false_type{});
-                else        frames(std::true_type{});
-                if (lane < SY_TW) mydof[lane] = Dk;
             }
-            fs_lds_barrier();
+#pragma unroll
+            for (int c = 0; c < SY_TW; ++c) {
+                rgv[c] = has ? ring[c] : make_float2(FS_NEG, FS_NEG);
+                if (!BETA_ONLY) { cov[c] = myoff[c]; nyv[c] = mynrm[c]; }
+            }
+            const double sdg = tdg[wb * 2 + buf];
+            const float sdr = tdr[wb * 2 + buf];
+            const double mdg = Dg;
+            const float mdr = drift;
+            const float D0 = has ? (float)(sdg - Dg) : 0.f, dl = has ? sdr - drift : 0.f;
+            const double Dlz = Dg - logz;
+            const float bl = q.blank2 - drift;
+            auto frames = [&](auto tail) {
+                constexpr bool TAIL = decltype(tail)::value;
+#pragma unroll
+                for (int c = SY_TW - 1; c >= 0; --c) {
+                    const int y = y0 + c, k = SY_TW - c;                               // k-th frame of the tile
+                    if (TAIL && y >= ty) {                                           // uniform: padding frames (all log 0, drift 0)
+                        ov[c & 3] = 0.f;
+                        if ((c & 3) == 0) dgr4[c >> 2] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                        myg[mgs * c] = make_float2(FS_NEG, FS_NEG);
+                        continue;
+                    }
+                    const float x = xv[c];
+                    float bT, bB;
+                    if (TAIL && y == ty - 1) {                                       // uniform branch
+                        bT = (row == tx - 1) ? 0.f : FS_NEG;
+                        bB = (row == tx) ? 0.f : FS_NEG;
+                    } else {
+                        // beta_B(r) = lse(g_B(r), g_T(r)) -- and that is also everything a token state of the row ABOVE can
+                        // continue into below itself: beta_T(r) = lse(g_T(r), beta_B(r+1)).  Four transcendentals a frame
+                        // (the three-way sum over the neighbour's two states took six), one lane shift instead of two.
+                        bB = fs_lae2(gB, gT);
+                        bT = fs_lae2(gT, fs_from_lane_above(FS_NEG, bB));
+                    }
+                    if (BETA_ONLY) {
+                        ov[c & 3] = bT - drift;                       // relative to the D of this frame (Dg + k * drift)
+                    } else {
+                        const float st = (float)(cov[c] + Dlz) + (float)(k - 1) * drift;   // C_w[y] + D_w - log Z
+                        const float occ = __builtin_amdgcn_exp2f(alv[c] + bT + st);  // 2^(-1e30) = 0
+                        ov[c & 3] = __builtin_amdgcn_exp2f(x - nyv[c]) - occ;        // (rows past the text: 0 - 0)
+                    }
+                    if ((c & 3) == 0) dgr4[c >> 2] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                    const float conv = D0 + (float)k * dl;
+                    const float nT = ghost ? rgv[c].y + conv : bT + (x - drift);
+                    const float nB = ghost ? rgv[c].x + conv : bB + bl;
+                    myg[mgs * c] = make_float2(nB, nT);
+                    gT = nT;
+                    gB = nB;
+                }
+            };
+            if (kt != 0) frames(std::false_type{});
+            else         frames(std::true_type{});
+            {
+                float mx = fs_wave_max_dpp(fmaxf(gT, gB));
+                if (mx < 0.5f * FS_NEG) mx = 0.f;
+                Dg += (double)RB * (double)drift + (double)mx;
+                drift += mx * (1.0f / RB);
+                gT = fmaxf(gT - mx, FS_NEG);
+                gB = fmaxf(gB - mx, FS_NEG);
+            }
+            if (lane == 0) { tdg[w * 2 + buf] = mdg; tdr[w * 2 + buf] = mdr; }
+            if (lane < SY_TW) tdof[(w * 2 + buf) * SY_TW + lane] = mdg + (double)(SY_TW - lane) * (double)mdr;
         }
+        fs_lds_barrier();
     }
 }
 
@@ -1846,10 +1887,13 @@ static int fs_launch_ctc(const CtcParams &q, bool backward, hipStream_t s) {
 
 template <int SY_NW, int SY_TW>
 static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
-    constexpr int SY_TILE = SY_TW * SY_LD, SY_THREADS = 2 * SY_NW * 64;
-    const size_t lds_f = (size_t)2 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)SY_NW * 2 * SY_TW * sizeof(double) + SY_TW * sizeof(double);
-    const size_t lds_b = (size_t)3 * SY_NW * 2 * SY_TILE * sizeof(float) + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) +
-                         (size_t)SY_NW * 2 * SY_TW * (sizeof(float2) + sizeof(float)) + (size_t)SY_NW * 64 * sizeof(float2);
+    constexpr int SY_THREADS = 2 * SY_NW * 64;
+    constexpr size_t tile = (size_t)64 * (SY_TW + 4) * sizeof(float);                                // slot-major, pitch TW + 4
+    const size_t lds_f = 2 * SY_NW * 2 * tile + (size_t)SY_NW * 2 * SY_TW * sizeof(double) + (size_t)SY_NW * 2 * sizeof(double) +
+                         64 * sizeof(double) + (size_t)SY_NW * 2 * sizeof(float);
+    const size_t lds_b = 3 * SY_NW * 2 * tile + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) + (size_t)SY_NW * 2 * sizeof(double) +
+                         (size_t)SY_NW * 2 * SY_TW * (sizeof(float2) + sizeof(float)) + (size_t)SY_NW * 64 * sizeof(float2) +
+                         (size_t)SY_NW * 2 * sizeof(float);
     hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 63) / 64, q.f.B), dim3(256), 0, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
     auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
