@@ -72,6 +72,11 @@ __device__ __forceinline__ float fs_lae2(float a, float b) {
 
 // a log-prob on its way into LDS: base 2, and never below FS_NEG (a -inf score would meet FS_NEG as NaN)
 __device__ __forceinline__ float fs_in(float lp) { return fmaxf(lp * FS_LOG2E, FS_NEG); }
+// the systolic kernels' stagers leave the scaling to the sweeper (an fma where it had a subtraction: free there, while a
+// stager's VALU issues land on the SIMD its sweeper's dependent chain runs on): natural logs in LDS, never below
+// FS_NEG_NAT (x log2 e = FS_NEG), rows past the text exactly that
+constexpr float FS_NEG_NAT = -6.9314718e29f;
+__device__ __forceinline__ float fs_nat(float lp) { return fmaxf(lp, FS_NEG_NAT); }
 
 // workgroup barrier for LDS traffic only: __syncthreads() would also wait for the stagers' global
 // stores (vmcnt(0)), a memory round trip per tile
@@ -194,6 +199,7 @@ __device__ __forceinline__ void fs_stager_by_hand(const float *in_g, float *out_
         mtail[j] = __builtin_amdgcn_ballot_w64(sv && qd[j] < tailq);
         rowok[j] = rs < tx;                                   // rows past the text are staged as log 0
     }
+    const bool allok = (BACKWARD ? 63 * w + 63 : 63 * w + 62) < tx;           // (uniform: most waves select nothing)
     auto tile_of = [&](int k) { return BACKWARD ? ntl - 1 - k : k; };          // k-th tile in sweep order
     auto issue = [&](int k, fs_u32x4 (&s)[NJ]) {
         const int t = tile_of(k < ntl ? k : ntl - 1);
@@ -216,7 +222,7 @@ __device__ __forceinline__ void fs_stager_by_hand(const float *in_g, float *out_
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const unsigned raw = s[j][jj];        // (bit_cast straight from the vector element reads element 0)
-                    f[jj] = rowok[j] ? fs_in(__builtin_bit_cast(float, raw)) : FS_NEG;
+                    f[jj] = (allok || rowok[j]) ? fs_nat(__builtin_bit_cast(float, raw)) : FS_NEG_NAT;
                 }
                 *reinterpret_cast<float4 *>(dst + rr[j] * PITCH + 4 * qd[j]) = make_float4(f[0], f[1], f[2], f[3]);   // one ds_write_b128
             }
@@ -601,7 +607,7 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_in(v[i]) : FS_NEG;   // rows past the text: log 0
+                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_nat(v[i]) : FS_NEG_NAT;   // rows past the text: log 0
                 }
                 stage_issue(tl + 2, v);
             }
@@ -680,7 +686,7 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
                         const float up = fs_from_lane_below(FS_NEG, prev);
                         float m;
                         asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(prev), "v"(up));
-                        const float base = m + (lpv[c] - drift);
+                        const float base = m + fmaf(lpv[c], FS_LOG2E, -drift);             // (the staged value is a natural log)
                         float v = base + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(prev - up)));
                         if (TAIL && y >= ty) v = FS_NEG;                             // uniform
                         const float gh = rgv[c] + (D0 + (float)k * dl);              // the sender's value, on this wave's offset
@@ -841,7 +847,7 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_in(q.v[i]) : FS_NEG;     // rows past the text: log 0
+                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_nat(q.v[i]) : FS_NEG_NAT;     // rows past the text: log 0
                     if (!BETA_ONLY) dal[r * PITCH + c] = q.u[i];
                 }
                 if (!BETA_ONLY && lane < SY_TW) toff[(w * 2 + (kl & 1)) * SY_TW + lane] = (y0 + lane < ty) ? q.o : 0.0;
@@ -956,7 +962,7 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
                             const float st = (float)(cov[c] + Dlz) + (float)(k - 1) * drift;
                             ov[c & 3] = -__builtin_amdgcn_exp2f(alv[c] + beta + st);        // 2^(-1e30) = 0
                         }
-                        const float gv = beta + (lpv[c] - drift);
+                        const float gv = beta + fmaf(lpv[c], FS_LOG2E, -drift);
                         const float gh = rgv[c] + (D0 + (float)k * dl);              // the sender's value, on this wave's offset
                         const float gn = ghost ? gh : gv;
                         gq[c & 3] = gn;
@@ -1446,7 +1452,7 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_in(vnext[i]) : FS_NEG;   // rows past the text: log 0
+                    dst[r * PITCH + c] = (63 * w + r - 1 < tx) ? fs_nat(vnext[i]) : FS_NEG_NAT;   // rows past the text: log 0
                 }
                 stage_issue(tl + 1);
             }
@@ -1503,7 +1509,7 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
                     const float upT = fs_from_lane_below(FS_NEG, pT);
                     const float L = fs_lae2(pB, upT);
                     float vb = L + bl;
-                    float vt = fs_lae2(pT, L) + (xv[c] - drift);
+                    float vt = fs_lae2(pT, L) + fmaf(xv[c], FS_LOG2E, -drift);       // (the staged score is a natural log)
                     if (TAIL && y >= ty) { vb = FS_NEG; vt = FS_NEG; }                  // uniform
                     const float gh = rgv[c] + (D0 + (float)k * dl);                    // the sender's value, on this wave's offset
                     const float nT = ghost ? gh : vt;
@@ -1620,7 +1626,7 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
 #pragma unroll
                 for (int i = 0; i < SY_TW; ++i) {
                     const int e = lane + 64 * i, r = e / SY_TW, c = e - r * SY_TW;
-                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_in(vnext[i]) : FS_NEG;   // rows past the text: log 0
+                    dlp[r * PITCH + c] = (63 * w + r < tx) ? fs_nat(vnext[i]) : FS_NEG_NAT;   // rows past the text: log 0
                     if (!BETA_ONLY) dal[r * PITCH + c] = unext[i];
                 }
                 if (!BETA_ONLY && lane < SY_TW) {
@@ -1714,11 +1720,11 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
                     } else {
                         const float st = (float)(cov[c] + Dlz) + (float)(k - 1) * drift;   // C_w[y] + D_w - log Z
                         const float occ = __builtin_amdgcn_exp2f(alv[c] + bT + st);  // 2^(-1e30) = 0
-                        ov[c & 3] = __builtin_amdgcn_exp2f(x - nyv[c]) - occ;        // (rows past the text: 0 - 0)
+                        ov[c & 3] = __builtin_amdgcn_exp2f(fmaf(x, FS_LOG2E, -nyv[c])) - occ;   // (rows past the text: 0 - 0)
                     }
                     if ((c & 3) == 0) dgr4[c >> 2] = make_float4(ov[0], ov[1], ov[2], ov[3]);
                     const float conv = D0 + (float)k * dl;
-                    const float nT = ghost ? rgv[c].y + conv : bT + (x - drift);
+                    const float nT = ghost ? rgv[c].y + conv : bT + fmaf(x, FS_LOG2E, -drift);
                     const float nB = ghost ? rgv[c].x + conv : bB + bl;
                     myg[mgs * c] = make_float2(nB, nT);
                     gT = nT;

@@ -11,6 +11,45 @@ __device__ __forceinline__ float dpp_below(float edge, float src) {
 }
 __device__ __forceinline__ int dpp_below_i(int edge, int src) { return __builtin_amdgcn_update_dpp(edge, src, 0x138, 0xf, 0xf, false); }
 
+__device__ __forceinline__ float lae2(float a, float b) {
+    float m;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(a - b)));
+}
+__device__ __forceinline__ float lae3(float a, float b, float c) {
+    const float m = fmaxf(fmaxf(a, b), c);
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
+}
+// the CTC form's frame: two states a row.  MODE 2: B' = blank + lse(B, T^), T' = x + lse3(T, B, T^) (six transcendentals, two
+// independent chains); MODE 3: L = lse(B, T^), B' = blank + L, T' = x + lse(T, L) (four, one longer chain)
+template <int MODE>
+__global__ void kctc(const float *lp, float *out, long long *cyc, int T) {
+    const int lane = threadIdx.x;
+    float pT = -1e30f, pB = lane == 0 ? 0.f : -1e30f;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int y0 = 0; y0 < T; y0 += 16) {
+        float l[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) l[c] = lp[(y0 + c) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float up = dpp_below(-1e30f, pT);
+            if (MODE == 2) {
+                const float vb = lae2(pB, up) - 1.5f;
+                const float vt = lae3(pT, pB, up) + l[c];
+                pB = vb; pT = vt;
+            } else {
+                const float L = lae2(pB, up);
+                pT = lae2(pT, L) + l[c];
+                pB = L - 1.5f;
+            }
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    out[lane] = pT + pB;
+    if (lane == 0) cyc[0] = t1 - t0;
+}
+
 template <int MODE>
 __global__ void k(const float *lp, float *out, long long *cyc, int T, int extra) {
     const int lane = threadIdx.x;
@@ -77,5 +116,11 @@ int main() {
         hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(o1, out, 256, hipMemcpyDeviceToHost);
         printf("LIN form%s: %.1f cycles/frame   out[5] = %f\n", extra ? " + store value" : "", (double)c / T, o1[5]);
     }
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kctc<2>, dim3(1), dim3(64), 0, 0, lp, out, cyc, T);
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(o0, out, 256, hipMemcpyDeviceToHost);
+    printf("CTC frame, lse3 + lse2 (6 transcendentals): %.1f cycles/frame   out[5] = %f\n", (double)c / T, o0[5]);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kctc<3>, dim3(1), dim3(64), 0, 0, lp, out, cyc, T);
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(o1, out, 256, hipMemcpyDeviceToHost);
+    printf("CTC frame, shared lse (4 transcendentals):  %.1f cycles/frame   out[5] = %f\n", (double)c / T, o1[5]);
     return 0;
 }
