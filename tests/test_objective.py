@@ -336,3 +336,26 @@ def test_forward_sum_side_by_side_sweeps_equal_the_serial_form(dev, request, B, 
         assert not grad_p[b, int(tx[b]):].any() and not grad_p[b, :, int(ty[b]):].any()
     if B > 2:
         assert not grad_p[1].any() and torch.isinf(loss_p[1])
+
+
+# The systolic kernels' stagers issue 16-byte global accesses by hand when T_mel % 4 == 0 and the tensors are 16-byte
+# aligned; anything else takes the compiler-scheduled stager.  A log-prob tensor that starts 4 bytes into its buffer must
+# give the same numbers (and no misaligned access).
+@gpu
+@pytest.mark.parametrize("blank", [None, -1.0])
+def test_forward_sum_on_a_tensor_that_is_not_16_byte_aligned(dev, blank):
+    import aligner_amd
+    rng = np.random.default_rng(77)
+    B, Tx, Ty = 3, 100, 240
+    lp = torch.from_numpy(_rand_logp(rng, B, Tx, Ty)).to(dev)
+    buf = torch.empty(B * Tx * Ty + 1, dtype=torch.float32, device=dev)
+    off = buf[1:].view(B, Tx, Ty)
+    off.copy_(lp)
+    assert off.data_ptr() % 16 == 4 and off.is_contiguous()
+    tx = torch.tensor([Tx, 37, 90], dtype=torch.int32)
+    ty = torch.tensor([Ty, 200, 91], dtype=torch.int32)
+    loss_a, grad_a = aligner_amd.forward_sum(lp, tx, ty, blank_logprob=blank)
+    loss_o, grad_o = aligner_amd.forward_sum(off, tx, ty, blank_logprob=blank)
+    torch.cuda.synchronize()
+    assert torch.allclose(loss_a, loss_o, rtol=1e-6, atol=1e-5)
+    assert bool(((grad_a - grad_o).abs() <= 2e-4 * grad_a.abs() + (2e-6 if blank is None else 2e-4)).all())
