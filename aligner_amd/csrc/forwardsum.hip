@@ -1020,41 +1020,69 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_both_sys_kernel(FwdSumP
     else                fwdsum_forward_sys_body<SY_NW, SY_TW>(p, b);
 }
 
-// gradient = -posterior = -2^(alpha + beta - log Z), in place over the beta the sweep left in p.grad: four frames of one
-// text row per thread (16-byte accesses when T_mel allows), the offsets of the row's wave (C_w forward, D_w backward:
-// one pair per frame, shared by the wave's 63 rows -- L2 hits).  Rows >= t_x, frames >= t_y, utterances without an
-// alignment: 0.
-__global__ __launch_bounds__(256) void fwdsum_combine_kernel(FwdSumParams p) {
-    const int b = blockIdx.z, r = blockIdx.y;
-    const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (y0 >= p.Ty) return;
+// gradient = -posterior = -2^(alpha + beta - log Z), in place over the beta the sweep left in p.grad.  A workgroup takes
+// 256 frames of one wave's 63 text rows: the per-frame term C_w[y] + D_w[y] - log Z (three doubles) is worked out ONCE
+// into LDS, then four rows at a time stream through -- 16-byte loads of alpha and beta, one exp2, a 16-byte store.
+// (One thread per four cells with its own offsets read 64 bytes of offsets per 32 bytes of operands.)  CTC: the same with
+// the softmax term 2^(x - n_y) in front (fwdsum_ctc_backward_sys_body's line).  Rows >= t_x, frames >= t_y, utterances
+// without an alignment: 0.
+template <bool CTC>
+__device__ __forceinline__ void fwdsum_combine_body(const FwdSumParams &p, const float *nrm) {
+    __shared__ float st[256], ny[256];
+    const int b = blockIdx.z, w = blockIdx.y, tid = threadIdx.x;
+    const int yb = blockIdx.x * 256;
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
     const bool ok = tx >= 1 && tx <= ty;
-    const size_t o = ((size_t)b * p.Tx + r) * p.Ty + y0;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    const int n = p.Ty - y0 < 4 ? p.Ty - y0 : 4;
-    const bool vec = n == 4 && ((reinterpret_cast<uintptr_t>(p.alpha + o) | reinterpret_cast<uintptr_t>(p.grad + o)) & 15) == 0;
-    if (ok && r < tx && y0 < ty) {
-        const int w = r / 63;
-        const double *C = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
-        const double *D = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
-        const double lz = p.logz[b];
-        float al[4], be[4];
-        if (vec) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(p.alpha + o), b4 = *reinterpret_cast<const float4 *>(p.grad + o);
-            al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
-            be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
-        } else {
-            for (int j = 0; j < n; ++j) { al[j] = p.alpha[o + j]; be[j] = p.grad[o + j]; }
+    {
+        const int y = yb + tid;
+        float v = 0.f, n = 0.f;
+        if (ok && y < ty) {
+            const size_t oi = ((size_t)b * SY_NW_MAX + w) * p.NT + y;
+            v = (float)(p.offs[oi] + p.doffs[oi] - p.logz[b]);
+            if (CTC) n = nrm[(size_t)b * p.Ty + y];
         }
-        for (int j = 0; j < n; ++j)
-            if (y0 + j < ty) g[j] = -__builtin_amdgcn_exp2f(al[j] + be[j] + (float)(C[j] + D[j] - lz));
+        st[tid] = v;
+        if (CTC) ny[tid] = n;
     }
-    if (vec) *reinterpret_cast<float4 *>(p.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
-    else for (int j = 0; j < n; ++j) p.grad[o + j] = g[j];
+    __syncthreads();
+    const int tq = tid & 63, rl = tid >> 6;
+    const int y0 = yb + 4 * tq;
+    if (y0 >= p.Ty) return;
+    const int n4 = p.Ty - y0 < 4 ? p.Ty - y0 : 4;
+    const int r1 = 63 * w + 63 < p.Tx ? 63 * w + 63 : p.Tx;
+    const bool al16 = n4 == 4 && p.Ty % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(p.alpha) | reinterpret_cast<uintptr_t>(p.grad) | reinterpret_cast<uintptr_t>(p.logp)) & 15) == 0;
+#pragma unroll 2
+    for (int r = 63 * w + rl; r < r1; r += 4) {
+        const size_t o = ((size_t)b * p.Tx + r) * p.Ty + y0;
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok && r < tx && y0 < ty) {
+            float al[4], be[4], x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (al16) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(p.alpha + o), b4 = *reinterpret_cast<const float4 *>(p.grad + o);
+                al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
+                be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
+                if (CTC) {
+                    const float4 x4 = *reinterpret_cast<const float4 *>(p.logp + o);
+                    x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
+                }
+            } else {
+                for (int j = 0; j < n4; ++j) { al[j] = p.alpha[o + j]; be[j] = p.grad[o + j]; if (CTC) x[j] = p.logp[o + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < n4 && y0 + j < ty) {
+                    const float occ = __builtin_amdgcn_exp2f(al[j] + be[j] + st[4 * tq + j]);
+                    g[j] = CTC ? __builtin_amdgcn_exp2f(fs_in(x[j]) - ny[4 * tq + j]) - occ : -occ;
+                }
+        }
+        if (al16) *reinterpret_cast<float4 *>(p.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
+        else for (int j = 0; j < n4; ++j) p.grad[o + j] = g[j];
+    }
 }
+__global__ __launch_bounds__(256) void fwdsum_combine_kernel(FwdSumParams p) { fwdsum_combine_body<false>(p, nullptr); }
 
 // --------------------------------------------------------------------------
 // The CTC form of the objective (the published one: OTA's ForwardSumLoss, README.md:21-25,50 -- a blank column
@@ -1762,45 +1790,8 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_both_sys_kernel(Ctc
 }
 
 // ... and its gradient, in place over the token states' beta: softmax over blank + text of the frame minus the token's
-// occupancy, d loss / d x[r,y] = 2^(x[r,y] - n_y) - 2^(alpha + beta - log Z)   (fwdsum_ctc_backward_sys_body's line).
-__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) {
-    const FwdSumParams &p = q.f;
-    const int b = blockIdx.z, r = blockIdx.y;
-    const int y0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (y0 >= p.Ty) return;
-    int tx = p.t_xs[b], ty = p.t_ys[b];
-    tx = tx > p.Tx ? p.Tx : tx;
-    ty = ty > p.Ty ? p.Ty : ty;
-    const bool ok = tx >= 1 && tx <= ty;
-    const size_t o = ((size_t)b * p.Tx + r) * p.Ty + y0;
-    float g[4] = {0.f, 0.f, 0.f, 0.f};
-    const int n = p.Ty - y0 < 4 ? p.Ty - y0 : 4;
-    const bool vec = n == 4 && ((reinterpret_cast<uintptr_t>(p.alpha + o) | reinterpret_cast<uintptr_t>(p.grad + o) |
-                                 reinterpret_cast<uintptr_t>(p.logp + o)) & 15) == 0;
-    if (ok && r < tx && y0 < ty) {
-        const int w = r / 63;
-        const double *C = p.offs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
-        const double *D = p.doffs + ((size_t)b * SY_NW_MAX + w) * p.NT + y0;
-        const float *ny = q.nrm + (size_t)b * p.Ty + y0;
-        const double lz = p.logz[b];
-        float al[4], be[4], x[4];
-        if (vec) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(p.alpha + o), b4 = *reinterpret_cast<const float4 *>(p.grad + o);
-            const float4 x4 = *reinterpret_cast<const float4 *>(p.logp + o);
-            al[0] = a4.x; al[1] = a4.y; al[2] = a4.z; al[3] = a4.w;
-            be[0] = b4.x; be[1] = b4.y; be[2] = b4.z; be[3] = b4.w;
-            x[0] = x4.x; x[1] = x4.y; x[2] = x4.z; x[3] = x4.w;
-        } else {
-            for (int j = 0; j < n; ++j) { al[j] = p.alpha[o + j]; be[j] = p.grad[o + j]; x[j] = p.logp[o + j]; }
-        }
-        for (int j = 0; j < n; ++j)
-            if (y0 + j < ty)
-                g[j] = __builtin_amdgcn_exp2f(fs_in(x[j]) - ny[j]) -
-                       __builtin_amdgcn_exp2f(al[j] + be[j] + (float)(C[j] + D[j] - lz));
-    }
-    if (vec) *reinterpret_cast<float4 *>(p.grad + o) = make_float4(g[0], g[1], g[2], g[3]);
-    else for (int j = 0; j < n; ++j) p.grad[o + j] = g[j];
-}
+// occupancy (fwdsum_combine_body<true>)
+__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) { fwdsum_combine_body<true>(q.f, q.nrm); }
 
 struct FsLayout { size_t alpha_off, offs_off, logz_off, doffs_off, total; int NT, R; };
 
@@ -1856,7 +1847,7 @@ static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
         hipLaunchKernelGGL(k2, dim3(2 * p.B), dim3(SY_THREADS), lds, s, p);
         ALIGNER_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(fwdsum_combine_kernel, dim3((p.Ty + 1023) / 1024, p.Tx, p.B), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(fwdsum_combine_kernel, dim3((p.Ty + 255) / 256, (p.Tx + 62) / 63, p.B), dim3(256), 0, s, p);
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     }
@@ -1910,7 +1901,7 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
         hipLaunchKernelGGL(k2, dim3(2 * q.f.B), dim3(SY_THREADS), lds, s, q);
         ALIGNER_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 1023) / 1024, q.f.Tx, q.f.B), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 255) / 256, (q.f.Tx + 62) / 63, q.f.B), dim3(256), 0, s, q);
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     }
