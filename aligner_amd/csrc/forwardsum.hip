@@ -1109,15 +1109,16 @@ struct CtcParams {
     FwdSumParams f;         // logp = the raw scores x; alpha = log2 alpha of the TOKEN states
     float *nrm;             // workspace [B,Ty]: n_y, base 2
     float blank2;           // blank score, base 2
+    int fused_norm;         // the sweeps-side-by-side launch: the normalisers come from extra workgroups of that same launch
+                            // (nobody needs them before the combining pass, which then also finishes the loss)
 };
 
 // n_y = log2( 2^blank + sum_{r < t_x} 2^x[r,y] ): 64 frames per workgroup, the rows dealt to its four waves (wave g takes
 // rows g, g+4, ...: four loads in flight per thread, a running (max, sum) pair), the four partial pairs met through LDS.
 // (One thread per frame over all rows was a chain of t_x dependent loads: 56 us at [64,200,1000], 1 TB/s.)
-__global__ __launch_bounds__(256) void ctc_colnorm_kernel(CtcParams q) {
+__device__ __forceinline__ void ctc_colnorm_body(const CtcParams &q, float (*sm)[64], float (*ss)[64], const int bx, const int b) {
     const FwdSumParams &p = q.f;
-    __shared__ float sm[4][64], ss[4][64];
-    const int b = blockIdx.y, fx = threadIdx.x & 63, g = threadIdx.x >> 6, y = blockIdx.x * 64 + fx;
+    const int fx = threadIdx.x & 63, g = threadIdx.x >> 6, y = bx * 64 + fx;
     int tx = p.t_xs[b], ty = p.t_ys[b];
     tx = tx > p.Tx ? p.Tx : tx;
     ty = ty > p.Ty ? p.Ty : ty;
@@ -1154,6 +1155,10 @@ __global__ __launch_bounds__(256) void ctc_colnorm_kernel(CtcParams q) {
         }
         q.nrm[(size_t)b * p.Ty + y] = M + __builtin_amdgcn_logf(S);
     }
+}
+__global__ __launch_bounds__(256) void ctc_colnorm_kernel(CtcParams q) {
+    __shared__ float sm[4][64], ss[4][64];
+    ctc_colnorm_body(q, sm, ss, blockIdx.x, blockIdx.y);
 }
 
 template <int R>
@@ -1446,7 +1451,7 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
     const int row = 63 * w + lane - 1;                        // sweeper: lane 0 is the ghost (row 63w-1)
     const bool ghost = lane == 0;
     if (!sweeper) {
-        if (w == 0) {                                         // the normalisers' sum, 64 partial sums (read in the last phase)
+        if (w == 0 && !q.fused_norm) {                        // the normalisers' sum, 64 partial sums (read in the last phase)
             double ns = 0.0;
             for (int y = lane; y < ty; y += 64) ns += (double)q.nrm[(size_t)b * p.Ty + y];
             tns[lane] = ns;
@@ -1548,11 +1553,13 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
                     if (TAIL && y == ty - 1) {                                           // uniform: Z = T_{tx-1} + B_tx
                         const float below = fs_from_lane_below(FS_NEG, pT);
                         if (row == tx && !ghost) {
-                            double ns = 0.0;
-                            for (int j = 0; j < 64; ++j) ns += tns[j];
                             const double lz = (double)fs_lae2(pB, below) + (Cg + (double)k * (double)drift);   // log2 Z of the raw scores
                             p.logz[b] = lz;
-                            p.loss[b] = (float)(-(lz - ns) * FS_LN2);
+                            if (!q.fused_norm) {                                         // (else: fwdsum_ctc_combine_kernel)
+                                double ns = 0.0;
+                                for (int j = 0; j < 64; ++j) ns += tns[j];
+                                p.loss[b] = (float)(-(lz - ns) * FS_LN2);
+                            }
                         }
                     }
                 }
@@ -1782,8 +1789,17 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_backward_sys_kernel
 }
 
 // the CTC form's sweeps side by side (see fwdsum_both_sys_kernel) ...
+// Workgroups beyond the 2B sweeping ones work out the frames' normalisers on the CUs the sweeps leave idle (the sweeps
+// never read them: the combining pass does, and finishes the loss).
 template <int SY_NW, int SY_TW>
 __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_both_sys_kernel(CtcParams q) {
+    if ((int)blockIdx.x >= 2 * q.f.B) {
+        extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+        if (threadIdx.x >= 256) return;
+        const int ncx = (q.f.Ty + 63) / 64, cb = (int)blockIdx.x - 2 * q.f.B;
+        ctc_colnorm_body(q, reinterpret_cast<float (*)[64]>(fs_smem), reinterpret_cast<float (*)[64]>(fs_smem + 256), cb % ncx, cb / ncx);
+        return;
+    }
     const int b = blockIdx.x >> 1;
     if (blockIdx.x & 1) fwdsum_ctc_backward_sys_body<SY_NW, SY_TW, true>(q, b);
     else                fwdsum_ctc_forward_sys_body<SY_NW, SY_TW>(q, b);
@@ -1791,7 +1807,27 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_both_sys_kernel(Ctc
 
 // ... and its gradient, in place over the token states' beta: softmax over blank + text of the frame minus the token's
 // occupancy (fwdsum_combine_body<true>)
-__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) { fwdsum_combine_body<true>(q.f, q.nrm); }
+__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) {
+    if (q.fused_norm && blockIdx.x == 0 && blockIdx.y == 0) {                 // loss = -(log Z - sum of the normalisers)
+        const FwdSumParams &p = q.f;
+        __shared__ double part[256];
+        const int b = blockIdx.z;
+        int tx = p.t_xs[b], ty = p.t_ys[b];
+        tx = tx > p.Tx ? p.Tx : tx;
+        ty = ty > p.Ty ? p.Ty : ty;
+        double ns = 0.0;
+        for (int y = threadIdx.x; y < ty; y += 256) ns += (double)q.nrm[(size_t)b * p.Ty + y];
+        part[threadIdx.x] = ns;
+        __syncthreads();
+        if (threadIdx.x == 0 && tx >= 1 && tx <= ty) {
+            double t = 0.0;
+            for (int j = 0; j < 256; ++j) t += part[j];
+            p.loss[b] = (float)(-(p.logz[b] - t) * FS_LN2);
+        }
+        __syncthreads();
+    }
+    fwdsum_combine_body<true>(q.f, q.nrm);
+}
 
 struct FsLayout { size_t alpha_off, offs_off, logz_off, doffs_off, total; int NT, R; };
 
@@ -1891,20 +1927,23 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
     const size_t lds_b = 3 * SY_NW * 2 * tile + (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) + (size_t)SY_NW * 2 * sizeof(double) +
                          (size_t)SY_NW * 2 * SY_TW * (sizeof(float2) + sizeof(float)) + (size_t)SY_NW * 64 * sizeof(float2) +
                          (size_t)SY_NW * 2 * sizeof(float);
-    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 63) / 64, q.f.B), dim3(256), 0, s, q);
-    ALIGNER_HIP_CHECK(hipGetLastError());
     auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_ctc_backward_sys_kernel<SY_NW, SY_TW>;
     if (backward && !g_opt_fwdsum_serial && fs_side_by_side(q.f.B) && q.f.doffs) {
         auto k2 = fwdsum_ctc_both_sys_kernel<SY_NW, SY_TW>;
         const size_t lds = lds_f > lds_b ? lds_f : lds_b;
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
-        hipLaunchKernelGGL(k2, dim3(2 * q.f.B), dim3(SY_THREADS), lds, s, q);
+        CtcParams qf = q;
+        qf.fused_norm = 1;
+        const unsigned ncol = (unsigned)((q.f.Ty + 63) / 64) * (unsigned)q.f.B;     // normaliser workgroups, behind the sweeps
+        hipLaunchKernelGGL(k2, dim3(2 * q.f.B + ncol), dim3(SY_THREADS), lds, s, qf);
         ALIGNER_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 255) / 256, (q.f.Tx + 62) / 63, q.f.B), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 255) / 256, (q.f.Tx + 62) / 63, q.f.B), dim3(256), 0, s, qf);
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     }
+    hipLaunchKernelGGL(ctc_colnorm_kernel, dim3((q.f.Ty + 63) / 64, q.f.B), dim3(256), 0, s, q);
+    ALIGNER_HIP_CHECK(hipGetLastError());
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
     hipLaunchKernelGGL(kf, dim3(q.f.B), dim3(SY_THREADS), lds_f, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
@@ -1972,7 +2011,7 @@ int aligner_forward_sum_ctc_f32(const float *scores, const int32_t *t_xs, const 
     CtcParams q{{scores, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off), reinterpret_cast<double *>(ws + L.offs_off),
                  reinterpret_cast<double *>(ws + L.logz_off), loss_out, grad_out, B, Tx, Ty, L.NT,
                  reinterpret_cast<double *>(ws + L.doffs_off)},
-                reinterpret_cast<float *>(ws + L.total), blank_logprob * FS_LOG2E};
+                reinterpret_cast<float *>(ws + L.total), blank_logprob * FS_LOG2E, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
     // rows 0..t_x: the blank after the last token needs a row of its own
