@@ -129,9 +129,6 @@ __device__ __forceinline__ float fs_bload(__amdgpu_buffer_rsrc_t r, unsigned vof
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 __device__ __forceinline__ void fs_bstore(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-#ifdef ALIGNER_EXP_FS_NOSTORE
-    if (v != 12345.f) return;          // experiment: the sweeps without their tile stores (results are garbage)
-#endif
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
 
