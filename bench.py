@@ -483,6 +483,13 @@ def run_c3(args, world: int):
         "similarity + log-softmax (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx), it, dev), 2.0 * Bc * Tx * Ty * Ca),
         "alignment search + dense path (maxpath_pipelined_kernel)": (event_time_us(lambda: aligner_amd.align(logp, tx, ty), it, dev), 0.0),
     }
+    # beside the step: what an OTA training step adds on the same log-probs -- the forward-sum objective with its gradient
+    # (published CTC form and plain form; both sweeps side by side in one launch + a combining pass)
+    beside = {
+        "forward-sum loss + gradient, CTC form (blank -1)": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty, blank_logprob=-1.0), it, dev),
+        "forward-sum loss only, CTC form": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty, want_grad=False, blank_logprob=-1.0), it, dev),
+        "forward-sum loss + gradient, plain form": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty), it, dev),
+    }
     dom = "text encoder conv 512->1024 k3 alone (split pass + conv_gemm_kernel, fp32 out)"     # the step's dominant launch pair
     tfl = stages[dom][1] / (stages[dom][0] * 1e-6) / 1e12
     ups = Bc * args.steps / elapsed
@@ -501,7 +508,8 @@ def run_c3(args, world: int):
                      "algorithmic_flops": stages[dom][1],
                      "note": "algorithmic flops of the fp32 convolution; the kernel issues three bf16 MFMAs per product "
                              "(hi*hi + hi*lo + lo*hi of the split operands), i.e. 3x these flops on the matrix cores",
-                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()}},
+                     "all_stages_us": {n: round(v[0], 2) for n, v in stages.items()},
+                     "not_in_the_step_us": {n: round(v, 2) for n, v in beside.items()}},
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = _cpu_dp_baseline(logp.cpu().numpy(), np.full(Bc, Tx, np.int32), np.full(Bc, Ty, np.int32),
