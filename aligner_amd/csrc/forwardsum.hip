@@ -1578,8 +1578,17 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
     }
 }
 
+// (fused_norm: workgroups beyond the B sweeping ones work out the frames' normalisers -- the sweep never reads them, the
+// loss does: fwdsum_ctc_loss_kernel behind this launch)
 template <int SY_NW, int SY_TW>
 __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_forward_sys_kernel(CtcParams q) {
+    if (q.fused_norm && (int)blockIdx.x >= q.f.B) {
+        extern __shared__ __attribute__((aligned(16))) float fs_smem[];
+        if (threadIdx.x >= 256) return;
+        const int ncx = (q.f.Ty + 63) / 64, cb = (int)blockIdx.x - q.f.B;
+        ctc_colnorm_body(q, reinterpret_cast<float (*)[64]>(fs_smem), reinterpret_cast<float (*)[64]>(fs_smem + 256), cb % ncx, cb / ncx);
+        return;
+    }
     fwdsum_ctc_forward_sys_body<SY_NW, SY_TW>(q, blockIdx.x);
 }
 
@@ -1804,25 +1813,27 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_ctc_both_sys_kernel(Ctc
 
 // ... and its gradient, in place over the token states' beta: softmax over blank + text of the frame minus the token's
 // occupancy (fwdsum_combine_body<true>)
-__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) {
-    if (q.fused_norm && blockIdx.x == 0 && blockIdx.y == 0) {                 // loss = -(log Z - sum of the normalisers)
-        const FwdSumParams &p = q.f;
-        __shared__ double part[256];
-        const int b = blockIdx.z;
-        int tx = p.t_xs[b], ty = p.t_ys[b];
-        tx = tx > p.Tx ? p.Tx : tx;
-        ty = ty > p.Ty ? p.Ty : ty;
-        double ns = 0.0;
-        for (int y = threadIdx.x; y < ty; y += 256) ns += (double)q.nrm[(size_t)b * p.Ty + y];
-        part[threadIdx.x] = ns;
-        __syncthreads();
-        if (threadIdx.x == 0 && tx >= 1 && tx <= ty) {
-            double t = 0.0;
-            for (int j = 0; j < 256; ++j) t += part[j];
-            p.loss[b] = (float)(-(p.logz[b] - t) * FS_LN2);
-        }
-        __syncthreads();
+// loss = -(log Z - sum of the frames' normalisers), summed in a fixed order (256 partial sums)
+__device__ __forceinline__ void fwdsum_ctc_finish_loss(const CtcParams &q, const int b) {
+    const FwdSumParams &p = q.f;
+    __shared__ double part[256];
+    int tx = p.t_xs[b], ty = p.t_ys[b];
+    tx = tx > p.Tx ? p.Tx : tx;
+    ty = ty > p.Ty ? p.Ty : ty;
+    double ns = 0.0;
+    for (int y = threadIdx.x; y < ty; y += 256) ns += (double)q.nrm[(size_t)b * p.Ty + y];
+    part[threadIdx.x] = ns;
+    __syncthreads();
+    if (threadIdx.x == 0 && tx >= 1 && tx <= ty) {
+        double t = 0.0;
+        for (int j = 0; j < 256; ++j) t += part[j];
+        p.loss[b] = (float)(-(p.logz[b] - t) * FS_LN2);
     }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void fwdsum_ctc_loss_kernel(CtcParams q) { fwdsum_ctc_finish_loss(q, blockIdx.x); }
+__global__ __launch_bounds__(256) void fwdsum_ctc_combine_kernel(CtcParams q) {
+    if (q.fused_norm && blockIdx.x == 0 && blockIdx.y == 0) fwdsum_ctc_finish_loss(q, blockIdx.z);
     fwdsum_combine_body<true>(q.f, q.nrm);
 }
 
@@ -1936,6 +1947,18 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
         hipLaunchKernelGGL(k2, dim3(2 * q.f.B + ncol), dim3(SY_THREADS), lds, s, qf);
         ALIGNER_HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(fwdsum_ctc_combine_kernel, dim3((q.f.Ty + 255) / 256, (q.f.Tx + 62) / 63, q.f.B), dim3(256), 0, s, qf);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        return ALIGNER_OK;
+    }
+    if (!backward && !g_opt_fwdsum_serial) {
+        // the loss alone: the normalisers from extra workgroups of the sweep's launch, the loss finished behind it
+        CtcParams qf = q;
+        qf.fused_norm = 1;
+        const unsigned ncol = (unsigned)((q.f.Ty + 63) / 64) * (unsigned)q.f.B;
+        ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kf), lds_f));
+        hipLaunchKernelGGL(kf, dim3(q.f.B + ncol), dim3(SY_THREADS), lds_f, s, qf);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(fwdsum_ctc_loss_kernel, dim3(q.f.B), dim3(256), 0, s, qf);
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     }
