@@ -515,13 +515,17 @@ __global__ __launch_bounds__(FS_THREADS) void fwdsum_backward_kernel(FwdSumParam
 // from the upper wave's alpha tile; backward: lane 63 = row 63w+63, read from the lower wave's g tile),
 // one barrier per tile.  Waves 4..7 stage: stager w moves wave w's tiles.
 //
-// Each wave keeps its OWN running offset (C_w forward, D_w backward; per-wave drift and re-basing keep
-// every row block near 0 whatever the others do), so a boundary value travels with its wave's offset
-// of that frame and is converted on arrival:  ghost = value + float(C_sender[y] - C_receiver[y]).
-// The workspace holds one offset per (wave, frame); posterior = exp2(alpha + beta + C_w[y] + D_w[y] - log Z).
+// Each wave keeps its OWN running offset (C_w forward, D_w backward; per-wave drift and one re-basing per tile keep
+// every row block near 0 whatever the others do).  Inside a tile the offset is linear, C_w(y) = Cg + k * drift, so a
+// boundary value travels with its wave's (Cg, drift) of that tile and is converted on arrival with one fma:
+// ghost = value + (float(Cg_sender - Cg_receiver) + k * (drift_sender - drift_receiver)).  The workspace holds one offset
+// per (wave, frame); posterior = exp2(alpha + beta + C_w[y] + D_w[y] - log Z).
+// Round 4: tiles slot-major in LDS (16-byte accesses on both sides), stagers issued by hand with counted
+// waits (fs_stager_by_hand), no per-row select and no double arithmetic in the frame loop, log2 e folded into the
+// sweeper's fma; with the gradient, both sweeps in one launch and a combining pass (fwdsum_both_sys_kernel).
 // --------------------------------------------------------------------------
 // NW sweeping waves (T_text <= 63 NW) and TW frames per tile: <4, 16> up to 252 rows, <8, 8> up to 504 (the
-// 16-wave workgroup has 128 VGPRs per lane and the backward kernel four tile arrays in LDS)
+// 16-wave workgroup has 128 VGPRs per lane and the backward kernel three tile arrays in LDS)
 
 template <int SY_NW, int SY_TW>
 __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, const int b) {
