@@ -1873,10 +1873,10 @@ static int fs_launch(const FwdSumParams &p, bool backward, hipStream_t s) {
     return ALIGNER_OK;
 }
 
-// Both sweeps in one launch pay when all 2B workgroups are resident at once, one per CU (measured at [B,200,1000]: B = 16
-// 106 us, 64 133 us against 215 one after the other; B = 128, exactly one workgroup per CU, 238: a single workgroup that
-// has to wait for a CU doubles the launch): up to three quarters of the CUs.
-static bool fs_side_by_side(int B) { return 8 * B <= 3 * device_cu_count(); }
+// Both sweeps in one launch pay while all 2B workgroups can be resident at once, one per CU (tools/fwdsum_batch_sweep.py at
+// [B,200,1000], side by side / one after the other: B = 96 117 / 187 us, 104 125 / 188, 112 169 / 198, 128 183 / 214; CTC form
+// 187 / 266 ... 258 / 275 -- past ~7/8 of the CUs some workgroup waits for a CU and the launch stretches, but it still wins).
+static bool fs_side_by_side(int B) { return 2 * B <= device_cu_count(); }
 
 template <int SY_NW, int SY_TW>
 static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
@@ -1889,7 +1889,7 @@ static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
     auto kf = fwdsum_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_backward_sys_kernel<SY_NW, SY_TW>;
     // with the gradient, on a batch that leaves half the CUs idle: both sweeps in one launch, then the combining pass
-    if (backward && !g_opt_fwdsum_serial && fs_side_by_side(p.B) && p.doffs) {
+    if (backward && g_opt_fwdsum_serial <= 0 && fs_side_by_side(p.B) && p.doffs) {
         auto k2 = fwdsum_both_sys_kernel<SY_NW, SY_TW>;
         const size_t lds = lds_f > lds_b ? lds_f : lds_b;
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
@@ -1941,7 +1941,7 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
                          (size_t)SY_NW * 2 * sizeof(float);
     auto kf = fwdsum_ctc_forward_sys_kernel<SY_NW, SY_TW>;
     auto kb = fwdsum_ctc_backward_sys_kernel<SY_NW, SY_TW>;
-    if (backward && !g_opt_fwdsum_serial && fs_side_by_side(q.f.B) && q.f.doffs) {
+    if (backward && g_opt_fwdsum_serial <= 0 && fs_side_by_side(q.f.B) && q.f.doffs) {
         auto k2 = fwdsum_ctc_both_sys_kernel<SY_NW, SY_TW>;
         const size_t lds = lds_f > lds_b ? lds_f : lds_b;
         ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(k2), lds));
@@ -1954,7 +1954,7 @@ static int fs_launch_ctc_sys(const CtcParams &q, bool backward, hipStream_t s) {
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     }
-    if (!backward && !g_opt_fwdsum_serial) {
+    if (!backward && g_opt_fwdsum_serial <= 0) {
         // the loss alone: the normalisers from extra workgroups of the sweep's launch, the loss finished behind it
         CtcParams qf = q;
         qf.fused_norm = 1;

@@ -346,7 +346,7 @@ int aligner_fused_align_f32(const float *keys_dev, const float *queries_dev,
  *   logp_dev [B,Tx,Ty] fp32 (Tx <= 1024), t_xs_dev/t_ys_dev [B] int32, loss_out_dev [B] fp32
  *   (+inf where t_x < 1 or t_x > t_y), grad_out_dev optional [B,Tx,Ty] fp32,
  *   workspace_dev aligner_forward_sum_workspace_bytes(B,Tx,Ty) bytes (the alpha tiles).
- * With the gradient, batches of at most 3/8 of the CU count run the alpha and the beta sweep side by side in one launch
+ * With the gradient, batches of at most half the CU count run the alpha and the beta sweep side by side in one launch
  * (beta travels through grad_out_dev) and a combining pass writes the gradient in place; larger batches run forward, then
  * backward.  Same results up to fp32 rounding of the exponent sum (tests/test_objective.py).  T_mel % 4 == 0 and 16-byte
  * aligned logp / grad pointers take the faster tile movers.
