@@ -14,12 +14,12 @@ import sys
 
 from .maxpath import Alignment, align, maximum_path, maximum_path_c, read_status  # noqa: F401
 from .softattn import (AlignmentEncoderParams, alignment_encoder, conv1d, soft_attention)  # noqa: F401
-from .objective import beta_binomial_prior, forward_sum, regulate  # noqa: F401
+from .objective import beta_binomial_prior, forward_sum, forward_sum_loss, regulate  # noqa: F401
 from .mobo import BoundarySearch, boundary_search, boundary_search_backward, soft_boundaries  # noqa: F401
 
 __all__ = ["Alignment", "align", "maximum_path", "maximum_path_c", "read_status",
            "soft_attention", "conv1d", "alignment_encoder", "AlignmentEncoderParams",
-           "forward_sum", "beta_binomial_prior", "regulate", "boundary_search", "boundary_search_backward", "soft_boundaries", "BoundarySearch", "install_dropin"]
+           "forward_sum", "forward_sum_loss", "beta_binomial_prior", "regulate", "boundary_search", "boundary_search_backward", "soft_boundaries", "BoundarySearch", "install_dropin"]
 
 
 def install_dropin() -> None:

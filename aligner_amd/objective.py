@@ -67,6 +67,39 @@ def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_g
     return loss, grad
 
 
+class _ForwardSumLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, t_x, t_y, blank_logprob):
+        need = logp.requires_grad
+        loss, grad = forward_sum(logp.detach(), t_x, t_y, want_grad=need, blank_logprob=blank_logprob)
+        ctx.save_for_backward(grad if need else None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (grad,) = ctx.saved_tensors
+        if grad is None or g_loss is None:
+            return None, None, None, None
+        return grad * g_loss.to(grad.dtype).view(-1, 1, 1), None, None, None
+
+
+def forward_sum_loss(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, blank_logprob: Optional[float] = -1.0,
+                     reduction: str = "mean") -> torch.Tensor:
+    """The OTA aligner's ForwardSumLoss as an autograd function on the GPU kernels: forward_sum() with its gradient
+    attached, so that `forward_sum_loss(logp, t_x, t_y).backward()` reaches whatever produced `logp` (the soft-attention
+    front end).  One launch pair computes loss AND gradient in the forward pass (both sweeps side by side); backward()
+    only scales.  blank_logprob = -1.0: the published CTC form (None: the plain monotonic form).  reduction: "mean" over
+    the batch (the paper's code: per-utterance CTC losses averaged), "sum" or "none"."""
+    loss = _ForwardSumLoss.apply(logp, t_x, t_y, blank_logprob)
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    if reduction == "none":
+        return loss
+    raise ValueError("reduction must be 'mean', 'sum' or 'none'")
+
+
 def beta_binomial_prior(t_x: torch.Tensor, t_y: torch.Tensor, T_text: int, T_mel: int, scaling: float = 1.0
                         ) -> torch.Tensor:
     """prior[B,T_text,T_mel]: BetaBinomial(n=t_x, a=s*(y+1), b=s*(t_y-y)).pmf(x); 0 in the padding."""

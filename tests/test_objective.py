@@ -359,3 +359,33 @@ def test_forward_sum_on_a_tensor_that_is_not_16_byte_aligned(dev, blank):
     torch.cuda.synchronize()
     assert torch.allclose(loss_a, loss_o, rtol=1e-6, atol=1e-5)
     assert bool(((grad_a - grad_o).abs() <= 2e-4 * grad_a.abs() + (2e-6 if blank is None else 2e-4)).all())
+
+
+@gpu
+@pytest.mark.parametrize("blank", [None, -1.0])
+def test_forward_sum_loss_is_differentiable_like_its_float64_restatement(dev, blank):
+    """forward_sum_loss (the OTA ForwardSumLoss on the kernels, attached to autograd): the gradient that reaches a leaf
+    BEHIND a log_softmax equals torch autograd through the float64 oracle restatement (the CTC form: torch's own ctc_loss)."""
+    import aligner_amd
+    rng = np.random.default_rng(3)
+    B, Tx, Ty = 3, 24, 60
+    z0 = rng.standard_normal((B, Tx, Ty))
+    tx = torch.tensor([Tx, 17, 9], dtype=torch.int32)
+    ty = torch.tensor([Ty, 44, 30], dtype=torch.int32)
+    z = torch.tensor(z0, dtype=torch.float32, device=dev, requires_grad=True)
+    loss = aligner_amd.forward_sum_loss(torch.log_softmax(z, dim=1), tx, ty, blank_logprob=blank, reduction="sum")
+    loss.backward()
+    zr = torch.tensor(z0, dtype=torch.float64, requires_grad=True)
+    lp = torch.log_softmax(zr, dim=1)
+    lpn = lp.detach().numpy()
+    if blank is None:
+        want_loss, want_grad = FS.forward_sum(lpn.astype(np.float32), tx.numpy(), ty.numpy())
+    else:
+        want_loss, want_grad = FS.ctc_forward_sum(lpn.astype(np.float32), tx.numpy(), ty.numpy(), blank)
+    lp.backward(gradient=torch.from_numpy(np.asarray(want_grad, dtype=np.float64)))     # the chain rule through log_softmax
+    total = float(np.sum(want_loss))
+    assert abs(float(loss.detach()) - total) <= 2e-3 + 1e-6 * abs(total)
+    assert torch.allclose(z.grad.cpu().double(), zr.grad, rtol=2e-3, atol=5e-5)
+    # no gradient asked for: the loss alone (one sweep)
+    l2 = aligner_amd.forward_sum_loss(torch.log_softmax(z.detach(), dim=1), tx, ty, blank_logprob=blank, reduction="none")
+    assert not l2.requires_grad and l2.shape == (B,)
