@@ -86,8 +86,8 @@ class _ForwardSumLoss(torch.autograd.Function):
 def forward_sum_loss(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, blank_logprob: Optional[float] = -1.0,
                      reduction: str = "mean") -> torch.Tensor:
     """The OTA aligner's ForwardSumLoss as an autograd function on the GPU kernels: forward_sum() with its gradient
-    attached, so that `forward_sum_loss(logp, t_x, t_y).backward()` reaches whatever produced `logp` (the soft-attention
-    front end).  One launch pair computes loss AND gradient in the forward pass (both sweeps side by side); backward()
+    attached, so that `forward_sum_loss(logp, t_x, t_y).backward()` reaches whatever differentiable torch code produced
+    `logp` (this package's `soft_attention()` kernel is forward-only: SURVEY 8 scopes the front end's forward pass).  One launch pair computes loss AND gradient in the forward pass (both sweeps side by side); backward()
     only scales.  blank_logprob = -1.0: the published CTC form (None: the plain monotonic form).  reduction: "mean" over
     the batch (the paper's code: per-utterance CTC losses averaged), "sum" or "none"."""
     loss = _ForwardSumLoss.apply(logp, t_x, t_y, blank_logprob)
