@@ -749,6 +749,9 @@ def main():
     done = [None, None]
     ge = args.gather_every
     if dist is not None:
+        # (a run shorter than a bucket gathers what it filled, not 96 slots of which 20 are used: the driver-shaped run's one
+        # collective is a fifth of the bytes)
+        ge = min(ge, max(args.steps, 1))
         ge = max(nstreams, (ge + nstreams - 1) // nstreams * nstreams)
         buckets = [torch.zeros((ge, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
         gathered = [torch.empty((world * ge, B, TX), dtype=torch.int32, device=dev) for _ in range(2)]
