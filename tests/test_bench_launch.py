@@ -48,3 +48,19 @@ def test_self_launch_starts_ranks_and_propagates_their_failure():
 def test_one_gpu_configs_refuse_n_ranks():
     r = _run(["--gpus", "2", "--config", "c3"], {"ALIGNER_BENCH_REHEARSE": "1"})
     assert r.returncode != 0 and "one-GPU" in r.stderr
+
+
+@pytest.mark.gpu
+def test_self_launched_two_ranks_on_one_gpu_print_one_line():
+    """On a GPU box: `bench.py --gpus 2` without a launcher starts two ranks itself (rehearsal form: both on GPU 0, the
+    gather over gloo), rank 0 prints ONE JSON line for n_gpus = 2 and every guard on the timed outputs holds -- incl. that
+    what the gather delivered for a rank is what that rank's kernels wrote."""
+    import json
+    r = _run(["--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-side-kernels"],
+             {"ALIGNER_BENCH_REHEARSE": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
+    assert d["guards"] and all(v is not False for v in d["guards"].values()) and d["guards"]["durations_match_gathered"] is True
