@@ -76,3 +76,19 @@ for (B, Tx, Ty, Cc) in ((64, 200, 1000, 512), (8, 500, 4000, 512)):
     print("[%d,%d,%d]: forward-sum loss %.1f us, with gradient %.1f us, beta-binomial prior %.1f us, length regulator (C=%d) %.1f us" % (
         B, Tx, Ty, ev(lambda: aligner_amd.forward_sum(lp, tx, ty, want_grad=False)), ev(lambda: aligner_amd.forward_sum(lp, tx, ty)),
         ev(lambda: aligner_amd.beta_binomial_prior(tx, ty, Tx, Ty)), Cc, ev(lambda: aligner_amd.regulate(h, dur, Ty))))
+
+# the drop-in call itself: maximum_path(value, mask) on GPU tensors, as a training step calls it (the lengths
+# come from the mask, the 0/1 path comes back in value's dtype) -- GPU time per call and host wall time per synchronous call
+import time
+B, Tx, Ty = 64, 200, 1000
+v = torch.from_numpy(synth.synth_value(B, Tx, Ty, 2)).to(dev)
+txr, tyr = lengths(B, Tx, 500, 1000, 2)
+mask = ((torch.arange(Tx, device=dev)[None, :, None] < txr[:, None, None]) & (torch.arange(Ty, device=dev)[None, None, :] < tyr[:, None, None])).to(v.dtype)
+full = torch.ones_like(v)
+for name, m in (("full-length mask", full), ("ragged mask", mask)):
+    t_gpu = ev(lambda: aligner_amd.maximum_path(v, m))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20):
+        aligner_amd.maximum_path(v, m); torch.cuda.synchronize()
+    t_wall = (time.perf_counter() - t0) / 20 * 1e6
+    print("drop-in maximum_path(value, mask) [64,200,1000], %s: %.1f us of GPU time per call, %.1f us wall per synchronous call" % (name, t_gpu, t_wall))
