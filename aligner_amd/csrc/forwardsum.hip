@@ -672,6 +672,12 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { scg[g] = tcg[(wu * 2 + buf) * NG + g]; sdr[g] = tdr[(wu * 2 + buf) * NG + g]; }
                 if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
+                {   // what the wave below converts with, and the offsets of the tile's frames for the workspace: known at the
+                    // tile's start (one re-basing per tile), so the LDS writes land under the frames, not before the barrier
+                    static_assert(NG == 1, "published before the frames: one group per tile");
+                    if (lane == 0) { tcg[(w * 2 + buf) * NG] = Cg; tdr[(w * 2 + buf) * NG] = drift; }
+                    if (lane < SY_TW) myoff[lane] = Cg + (double)(lane + 1) * (double)drift;
+                }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
                     float D0 = 0.f, dl = 0.f;
@@ -715,22 +721,6 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
                 if (y0 + SY_TW < ty) frames(std::false_type{});
                 else                 frames(std::true_type{});
                 if (p.stamps) { asm volatile("" :: "v"(prev)); c2 = __builtin_amdgcn_s_memtime(); }
-                // what the wave below converts with, and the offsets of the tile's frames for the workspace
-                if (lane < NG) {
-                    double cgp = mcg[0];
-                    float drp = mdr[0];
-#pragma unroll
-                    for (int g = 1; g < NG; ++g) { cgp = lane == g ? mcg[g] : cgp; drp = lane == g ? mdr[g] : drp; }
-                    tcg[(w * 2 + buf) * NG + lane] = cgp;
-                    tdr[(w * 2 + buf) * NG + lane] = drp;
-                }
-                if (lane < SY_TW) {
-                    double cgp = mcg[0];
-                    float drp = mdr[0];
-#pragma unroll
-                    for (int g = 1; g < NG; ++g) { cgp = lane / RB == g ? mcg[g] : cgp; drp = lane / RB == g ? mdr[g] : drp; }
-                    myoff[lane] = cgp + (double)((lane & (RB - 1)) + 1) * (double)drp;
-                }
                 if (p.stamps) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_amdgcn_s_memtime(); }
             }
             fs_lds_barrier();
@@ -924,6 +914,11 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
                 }
 #pragma unroll
                 for (int g = 0; g < NG; ++g) { sdg[g] = tdg[(wb * 2 + buf) * NG + g]; sdr[g] = tdr[(wb * 2 + buf) * NG + g]; }
+                {   // (published at the tile's start: see the forward kernel)
+                    static_assert(NG == 1, "published before the frames: one group per tile");
+                    if (lane == 0) { tdg[(w * 2 + buf) * NG] = Dg; tdr[(w * 2 + buf) * NG] = drift; }
+                    if (lane < SY_TW) mydof[lane] = Dg + (double)(RB - (lane & (RB - 1))) * (double)drift;
+                }
                 auto frames = [&](auto tail) {
                     constexpr bool TAIL = decltype(tail)::value;
                     float D0 = 0.f, dl = 0.f;
@@ -983,21 +978,6 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
                 };
                 if (kt != 0) frames(std::false_type{});
                 else         frames(std::true_type{});
-                if (lane < NG) {
-                    double dgp = mdg[0];
-                    float drp = mdr[0];
-#pragma unroll
-                    for (int g = 1; g < NG; ++g) { dgp = lane == g ? mdg[g] : dgp; drp = lane == g ? mdr[g] : drp; }
-                    tdg[(w * 2 + buf) * NG + lane] = dgp;
-                    tdr[(w * 2 + buf) * NG + lane] = drp;
-                }
-                if (lane < SY_TW) {                                                  // D of the tile's frames (BETA_ONLY: to the workspace)
-                    double dgp = mdg[0];
-                    float drp = mdr[0];
-#pragma unroll
-                    for (int g = 1; g < NG; ++g) { dgp = lane / RB == g ? mdg[g] : dgp; drp = lane / RB == g ? mdr[g] : drp; }
-                    mydof[lane] = dgp + (double)(RB - (lane & (RB - 1))) * (double)drp;
-                }
             }
             fs_lds_barrier();
         }
@@ -1535,6 +1515,8 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
             const float mdr = drift;
             const float D0 = w ? (float)(scg - Cg) : 0.f, dl = w ? sdr - drift : 0.f;
             const float bl = q.blank2 - drift;
+            if (lane == 0) { tcg[w * 2 + buf] = mcg; tdr[w * 2 + buf] = mdr; }           // (at the tile's start: see the plain form)
+            if (lane < SY_TW) toff[(w * 2 + buf) * SY_TW + lane] = mcg + (double)(lane + 1) * (double)mdr;
             auto frames = [&](auto tail) {
                 constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
@@ -1575,8 +1557,6 @@ __device__ __forceinline__ void fwdsum_ctc_forward_sys_body(const CtcParams &q, 
                 pT = fmaxf(pT - mx, FS_NEG);
                 pB = fmaxf(pB - mx, FS_NEG);
             }
-            if (lane == 0) { tcg[w * 2 + buf] = mcg; tdr[w * 2 + buf] = mdr; }
-            if (lane < SY_TW) toff[(w * 2 + buf) * SY_TW + lane] = mcg + (double)(lane + 1) * (double)mdr;
         }
         fs_lds_barrier();
     }
@@ -1737,6 +1717,8 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
             const float D0 = has ? (float)(sdg - Dg) : 0.f, dl = has ? sdr - drift : 0.f;
             const double Dlz = Dg - logz;
             const float bl = q.blank2 - drift;
+            if (lane == 0) { tdg[w * 2 + buf] = mdg; tdr[w * 2 + buf] = mdr; }           // (at the tile's start: see the plain form)
+            if (lane < SY_TW) tdof[(w * 2 + buf) * SY_TW + lane] = mdg + (double)(SY_TW - lane) * (double)mdr;
             auto frames = [&](auto tail) {
                 constexpr bool TAIL = decltype(tail)::value;
 #pragma unroll
@@ -1786,8 +1768,6 @@ __device__ __forceinline__ void fwdsum_ctc_backward_sys_body(const CtcParams &q,
                 gT = fmaxf(gT - mx, FS_NEG);
                 gB = fmaxf(gB - mx, FS_NEG);
             }
-            if (lane == 0) { tdg[w * 2 + buf] = mdg; tdr[w * 2 + buf] = mdr; }
-            if (lane < SY_TW) tdof[(w * 2 + buf) * SY_TW + lane] = mdg + (double)(SY_TW - lane) * (double)mdr;
         }
         fs_lds_barrier();
     }
