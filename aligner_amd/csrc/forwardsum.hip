@@ -660,8 +660,8 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
                 const int wu = w ? w - 1 : 0;
                 const float4 *ring4 = reinterpret_cast<const float4 *>(tout + (wu * 2 + buf) * SY_TILE + 63 * PITCH);
                 float lpv[SY_TW], rgv[SY_TW], av[4];
-                double scg[NG], mcg[NG];
-                float sdr[NG], mdr[NG];
+                double scg[NG];
+                float sdr[NG];
 #pragma unroll
                 for (int i = 0; i < SY_TW / 4; ++i) {
                     const float4 l4 = src4[i], r4 = ring4[i];
@@ -685,8 +685,6 @@ __device__ __forceinline__ void fwdsum_forward_sys_body(const FwdSumParams &p, c
                     for (int c = 0; c < SY_TW; ++c) {
                         const int y = y0 + c, g = c / RB, k = (c & (RB - 1)) + 1;
                         if (k == 1) {                                                // a group starts (uniform values)
-                            mcg[g] = Cg;
-                            mdr[g] = drift;
                             D0 = w ? (float)(scg[g] - Cg) : 0.f;
                             dl = w ? sdr[g] - drift : 0.f;
                         }
@@ -895,8 +893,8 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
                 // the whole tile's operands up front (one LDS latency per tile, not one per frame)
                 float lpv[SY_TW], alv[SY_TW], rgv[SY_TW], ov[4], gq[4];
                 double cov[SY_TW];
-                double sdg[NG], mdg[NG];
-                float sdr[NG], mdr[NG];
+                double sdg[NG];
+                float sdr[NG];
 #pragma unroll
                 for (int i = 0; i < SY_TW / 4; ++i) {
                     const float4 l4 = slp4[i], r4 = ring4[i];
@@ -927,8 +925,6 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
                     for (int c = SY_TW - 1; c >= 0; --c) {
                         const int y = y0 + c, g = c / RB, k = RB - (c & (RB - 1));   // k-th frame of its group
                         if (k == 1) {                                                // a group starts (uniform values)
-                            mdg[g] = Dg;
-                            mdr[g] = drift;
                             D0 = has ? (float)(sdg[g] - Dg) : 0.f;
                             dl = has ? sdr[g] - drift : 0.f;
                             Dlz = Dg - logz;
