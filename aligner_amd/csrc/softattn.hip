@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "aligner_amd.h"
 #include "common.h"
@@ -728,6 +729,504 @@ __global__ __launch_bounds__(SA_THREADS, (KS == 16 && MULTI) ? 1 : 2) void softa
                 }
             }
         }
+    }
+}
+
+// --------------------------------------------------------------------------
+// Row-tile form of the one-row-group case (Tx <= 32*NT): the kernel BASELINE configs[1] and [2] run.
+//
+// softattn_kernel<.,.,false> above gives a wave a strip of 32 frames and ALL row tiles: its first byte leaves the CU
+// after the text staging AND a whole strip's arithmetic, and since every workgroup of the grid starts together the
+// chip's memory system sees a read phase, a silent phase and a write phase (profiles/r02g_softattn_stamps.txt: the
+// first store at 15 k of 29.5 k cycles).  Here the roles are turned by 90 degrees:
+//   * wave w < NT owns ROW TILE w (32 text rows) for the whole kernel: its A fragments (bf16 hi / lo of K) live in
+//     registers -- the text operand never touches LDS -- and its 16 bias values (s2*|k_i|^2, -inf for masked rows) too;
+//   * the workgroup walks its 256 frames strip by strip (32 frames); for a strip every compute wave does the 3*KS
+//     MFMAs of ITS tile, the strip's softmax statistics (max, sum of 2^(x - max) per frame) meet through LDS: one
+//     barrier per strip, and each wave stores its own 32 x 32 tile.  The first stores leave one tile's arithmetic
+//     after the text operand arrived, and from then on stores, arithmetic and the next strips' loads overlap;
+//   * wave 0 is the loader: the mel strips come global -> LDS by LDS-DMA (raw fp32, all of them in flight at once, no
+//     registers) and the loader splits a landed strip into the B fragments (bf16 hi / lo) of a ring slot.  The compute
+//     waves are bound by their VALU issue (a SIMD issues one vector instruction per 4 cycles whichever of its two waves
+//     it comes from: 2 x ~290 instructions a strip were 2.4 k cycles), the loader's SIMD hosts one compute wave only:
+//     everything that is not a tile's own arithmetic belongs to the loader.
+// Barrier k (k = -1 .. NS-1) is the only synchronisation: before barrier k the loader has written strip k + 2's
+// fragments into its ring slot and every compute wave has published its statistics of strip k; after it the compute
+// waves read strip k + 1's fragments (ring of three slots: strip k + 2 is being written meanwhile) and strip k's
+// statistics (two buffers).
+// --------------------------------------------------------------------------
+constexpr int RT_STRIPS = 8;      // 32-frame strips per workgroup
+// raw strips in LDS (in flight by LDS-DMA).  16 channel groups of 5 k-steps: all of a workgroup's strips -- they are
+// fetched while the memory system is still idle (before the first stores), and the store phase is a pure write stream
+constexpr int rt_raw_slots(int KS) { return KS <= 5 ? RT_STRIPS : 4; }
+constexpr int RT_RING = 3;        // split strips in LDS
+// the log-probs are stored sc1: written through the XCD's L2, the line dropped from it.  Measured (rocprofv3, one batch at
+// a time, same box): plain 17.5 us, sc0 17.7, sc1 16.4, sc0 sc1 16.4, nt 29.3 (rows are 4000 bytes apart: a 128-byte
+// run straddles two lines); the search that reads them next is not slower (32.3 against 32.5 us: Infinity Cache)
+constexpr int RT_ST_AUX = 16;
+
+__device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses (sbase + voff) to LDS [lds_dst + 16*lane].  The
+// instruction's offset field moves BOTH addresses, so up to four 1 KB pieces share one M0 setting: piece i of a group
+// lands at lds_dst + 1024 i and its base pointer is passed less 1024 i (M0 save / restore and the wait states around
+// it were most of a piece's issue cost: ~50 cycles each, 60 pieces before the first strip could be waited for)
+template <int N>
+__device__ __forceinline__ void rt_dma_group(unsigned lds_dst, unsigned voff, const unsigned char *b0, const unsigned char *b1,
+                                             const unsigned char *b2, const unsigned char *b3) {
+    unsigned keep;
+    if (N == 4)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %5 offset:2048\n\tglobal_load_lds_dwordx4 %1, %6 offset:3072\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b0), "s"(b1 - 1024), "s"(b2 - 2048), "s"(b3 - 3072) : "memory");
+    else if (N == 2)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b0), "s"(b1 - 1024) : "memory");
+}
+// a [16 KS channels][32 positions] fp32 block global -> LDS: piece n = channels 8n .. 8n+7 (lane: channel 8n + lane/8,
+// positions 4 (lane%8) .. +3), `pstep` bytes between two pieces' channel groups in memory
+template <int KS>
+__device__ __forceinline__ void rt_dma_block(unsigned dst, unsigned voff, const unsigned char *base, size_t pstep) {
+    static_assert((2 * KS) % 4 == 0 || (2 * KS) % 4 == 2, "pieces in groups of four, then two");
+#pragma unroll
+    for (int g = 0; g + 4 <= 2 * KS; g += 4)
+        rt_dma_group<4>(dst + g * 1024, voff, base + g * pstep, base + (g + 1) * pstep, base + (g + 2) * pstep, base + (g + 3) * pstep);
+    if ((2 * KS) % 4 == 2)
+        rt_dma_group<2>(dst + (2 * KS - 2) * 1024, voff, base + (2 * KS - 2) * pstep, base + (2 * KS - 1) * pstep, nullptr, nullptr);
+}
+template <int CNT>
+__device__ __forceinline__ void rt_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
+
+// both halves of a wave combined: every lane gets (lower half's value, upper half's value) of its column
+__device__ __forceinline__ void rt_halves(float v, float &lo, float &hi) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];              // (bit_cast of a vector ELEMENT reads element 0: DESIGN.md rule 10)
+    lo = __builtin_bit_cast(float, r0);
+    hi = __builtin_bit_cast(float, r1);
+}
+
+// a word of LDS for the polls (a volatile access through a generic pointer is a FLAT load: it waits for vmcnt(0),
+// i.e. for every store the wave has in flight)
+typedef __attribute__((address_space(3))) unsigned rt_lds_u32;
+// "the frame's constant has not been published yet" (a quiet NaN no arithmetic produces)
+constexpr unsigned RT_PENDING = 0x7FC0DEADu;
+// the NT tiles' (max, sum of 2^(x - max)) of a frame merged: -(max + log2 sum) * ln2
+template <int NT>
+__device__ __forceinline__ float rt_merge(const float2 (&st)[NT]) {
+    float M = st[0].x;
+#pragma unroll
+    for (int w = 1; w < NT; ++w) M = fmaxf(M, st[w].x);
+    const float Mf = (M == NEG_INF_F) ? 0.f : M;
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT; ++w) L = fmaf(st[w].y, __builtin_amdgcn_exp2f(st[w].x - Mf), L);
+    return -(Mf + __builtin_amdgcn_logf(L)) * LN2_F;           // v_log_f32 = log2
+}
+
+// debug stamps: [workgroup][wave][64]: 0 entry, 1 operands staged, 2 first strip's MFMAs done, 5 end, 6 stores drained,
+// 4 / 7 drained / entry on the 100 MHz clock; 8 + 4j, 9 + 4j: arrival at / release from barrier j
+#define RT_STAMP(k)                                                                                           \
+    do {                                                                                                      \
+        if (p.stamps && (threadIdx.x & 63) == 0)                                                              \
+            p.stamps[((size_t)blockIdx.x * (NT + 1) + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+template <int KS, int NT, bool OUT16>
+__global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnParams p) {
+    constexpr int SLOTB = KS * 2048;                  // one strip: raw [16 KS channels][32 frames] fp32 == split [KS][hi, lo][64] x 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RT_RAW = rt_raw_slots(KS);
+    unsigned char *raw = smem;                                                     // [RT_RAW][SLOTB]
+    unsigned char *frg = smem + RT_RAW * SLOTB;                                    // [RT_RING][SLOTB]
+    float2 *stat = reinterpret_cast<float2 *>(frg + RT_RING * SLOTB);              // [2][NT][32] (max, sum) per frame
+    float *knl = reinterpret_cast<float *>(stat + 2 * NT * 32);                    // [NT][32] row terms
+    float *c0buf = knl + NT * 32;                                                  // [2][32] -lse*ln2 per frame, or RT_PENDING
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int NQ = (p.Ty + 32 * RT_STRIPS - 1) / (32 * RT_STRIPS);
+    int b, fq;
+    if ((p.B & 7) == 0) {                             // the workgroups of one utterance on one XCD (see softattn_kernel)
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        fq = slot % NQ;
+        b = (slot / NQ) * 8 + xcd;
+    } else {
+        b = blockIdx.x / NQ;
+        fq = blockIdx.x % NQ;
+    }
+    const int f0 = fq * 32 * RT_STRIPS;
+    const int left = p.Ty - f0;
+    const int NS = left >= 32 * RT_STRIPS ? RT_STRIPS : (left + 31) / 32;          // strips of this workgroup (>= 1)
+    const float *Qb = p.queries + (size_t)b * p.C * p.Ty;
+    RT_STAMP(0);
+    if (p.stamps && lane == 0)
+        p.stamps[((size_t)blockIdx.x * (NT + 1) + wave) * 64 + 7] = __builtin_amdgcn_s_memrealtime();
+
+    // wave 0 is the loader (the first wave's loads are the first the CU's load path serves: the first strip is out
+    // while the text tiles stream in); wave t + 1 owns row tile t
+    const int tile = wave - 1;
+    if (wave == 0) {
+        // ---------------- loader ----------------
+        const unsigned raw0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)raw;
+        const int cl = lane >> 3, q4 = lane & 7;      // DMA piece n: channel 8n + cl, frames 4*q4 .. 4*q4+3 of the strip
+        int issued = 0;                               // strips whose DMAs have been issued
+        auto issue_upto = [&](int n) {
+            for (; issued < n && issued < NS; ++issued) {
+                int fr = f0 + 32 * issued + 4 * q4;
+                fr = fr < p.Ty - 4 ? fr : p.Ty - 4;   // Ty % 4 == 0: a quad is all in or all out; frames past Ty: any valid quad
+                rt_dma_block<KS>(raw0 + (unsigned)(issued % RT_RAW) * SLOTB, 4u * (unsigned)(cl * p.Ty + fr),
+                                 reinterpret_cast<const unsigned char *>(Qb), (size_t)32 * p.Ty);
+            }
+        };
+        // raw strip s has landed: the DMAs of the strips issued after it may stay in flight (vmcnt counts instructions,
+        // in order; its field has 6 bits)
+        auto wait_for = [&](int s) {
+            const int later = issued - 1 - s;         // uniform
+            constexpr int P = 2 * KS;
+            if (later >= 5) rt_wait_vm<(5 * P < 63 ? 5 * P : 63)>();
+            else if (later == 4) rt_wait_vm<(4 * P < 63 ? 4 * P : 63)>();
+            else if (later == 3) rt_wait_vm<(3 * P < 63 ? 3 * P : 63)>();
+            else if (later == 2) rt_wait_vm<2 * P>();
+            else if (later == 1) rt_wait_vm<P>();
+            else rt_wait_vm<0>();
+        };
+        // raw strip s -> B fragments in ring slot s % RT_RING: lane (frame l31, channel half) takes channels
+        // 16k + 8 half + jj of k-step k.  All the LDS reads first, then the arithmetic
+        auto split = [&](int s) {
+            const float *R = reinterpret_cast<const float *>(raw + (s % RT_RAW) * SLOTB) + half * 8 * 32 + l31;
+            uint4 *F = reinterpret_cast<uint4 *>(frg + (s % RT_RING) * SLOTB) + lane;
+            float v[KS][8];
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[k][jj] = R[(16 * k + jj) * 32];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    __bf16 hv, lv;
+                    split_bf16(v[k][jj], hv, lv);
+                    h[jj] = hv;
+                    l[jj] = lv;
+                }
+                F[(2 * k) * 64] = __builtin_bit_cast(uint4, h);
+                F[(2 * k + 1) * 64] = __builtin_bit_cast(uint4, l);
+            }
+        };
+        // the NT tiles' statistics of strip s merged into the frame's constant -lse*ln2 (what the compute waves add
+        // to ln2 * logit): every wave needs it, one wave works it out
+        auto merge = [&](int s) {
+            float2 st[NT];
+#pragma unroll
+            for (int w = 0; w < NT; ++w) st[w] = stat[((s & 1) * NT + w) * 32 + l31];
+            c0buf[(s & 1) * 32 + l31] = rt_merge<NT>(st);
+        };
+        static_assert(RT_RAW <= 8, "wait_for's cases: at most 6 strips in flight");
+        c0buf[lane] = __builtin_bit_cast(float, RT_PENDING);      // both buffers
+        // The first two strips come through registers, in fragment order (lane: frame l31, channel half; channels
+        // 16k + 8 half + jj), and the loader converts them as they are: plain loads return 1.2 k cycles after the
+        // kernel's start, the first LDS-DMA instructions of a wave took 3 k cycles to issue.
+        float q0[KS][8], q1[KS][8];
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(Qb), 0, (unsigned)p.C * (unsigned)p.Ty * 4u, 0x00020000);
+        auto load_strip = [&](float (&v)[KS][8], int s) {
+            int cf = f0 + 32 * s + l31;
+            cf = cf < p.Ty ? cf : p.Ty - 1;
+            const unsigned vo = 4u * (unsigned)(8 * half * p.Ty + cf);
+#pragma unroll
+            for (int k = 0; k < KS; ++k)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    v[k][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo, 4u * (unsigned)((16 * k + jj) * p.Ty), 0));
+        };
+        auto to_ring = [&](const float (&v)[KS][8], int s) {
+            uint4 *F = reinterpret_cast<uint4 *>(frg + (s % RT_RING) * SLOTB) + lane;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    __bf16 hv, lv;
+                    split_bf16(v[k][jj], hv, lv);
+                    h[jj] = hv;
+                    l[jj] = lv;
+                }
+                F[(2 * k) * 64] = __builtin_bit_cast(uint4, h);
+                F[(2 * k + 1) * 64] = __builtin_bit_cast(uint4, l);
+            }
+        };
+        load_strip(q0, 0);
+        to_ring(q0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_strip(q1, 1);                            // (behind strip 0's conversion: nothing of it in front of the first strip)
+        RT_STAMP(1);
+        rt_barrier();                                 // barrier A: strip 0 is in the ring
+        issued = 2;
+        issue_upto(3);                                // strip 2 by LDS-DMA while strip 1's loads land; the others behind barrier B
+        RT_STAMP(11);
+        to_ring(q1, 1);
+        RT_STAMP(14);
+        rt_barrier();                                 // barrier B (= -1): strip 1 is in the ring
+        for (int j = 0; j < NS; ++j) {
+            if (j > 0) merge(j - 1);                  // first: the compute waves' stores of strip j-1 wait for it
+            if (lane < 32) c0buf[(j & 1) * 32 + lane] = __builtin_bit_cast(float, RT_PENDING);   // (strip j-2's: read before barrier j-1)
+            // strips < j + 2 have been split: their raw slots are free.  (Two more strips per iteration: the first
+            // iterations' splits must not wait behind sixty pieces' issue.)
+            issue_upto(2 * j + 5 < j + 2 + RT_RAW ? 2 * j + 5 : j + 2 + RT_RAW);
+            if (j + 2 < NS) {
+                wait_for(j + 2);
+                split(j + 2);
+            }
+            RT_STAMP(8 + 4 * j);
+            rt_barrier();                             // barrier j
+            RT_STAMP(9 + 4 * j);
+        }
+        merge(NS - 1);
+        RT_STAMP(5);
+        return;
+    }
+
+    // ---------------- compute wave: row tile `tile` ----------------
+    int tx = p.Tx;
+    if (p.t_xs) {
+        tx = p.t_xs[b];
+        tx = tx < 0 ? 0 : (tx > p.Tx ? p.Tx : tx);
+    }
+    const bool l2 = (p.sim == ALIGNER_SIM_L2);
+    const float scale = l2 ? -p.temperature : p.temperature;
+    const float s2 = scale * LOG2E_F;                 // logits are kept in base 2
+    const float dmul = l2 ? -2.0f * s2 : s2;
+    bf16x8 ah[KS], al[KS];
+    float4 bz[4];
+    // A fragments: lane (row i = 32 tile + l31, channel half) holds channels 16s + 8 half + jj.  The utterance's
+    // [C,Tx] block is a buffer resource: channels >= C read as zero.  Rows >= Tx read row Tx - 1 again (finite): their
+    // logits are -inf through the bias whatever the products are.
+    const int row_i = 32 * tile + l31;
+    float kv[KS][8];
+    {
+        const float *Kb = p.keys + (size_t)b * p.C * p.Tx;
+        {
+            const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(Kb), 0, (unsigned)p.C * (unsigned)p.Tx * 4u, 0x00020000);
+            const int ic = row_i < p.Tx ? row_i : p.Tx - 1;
+            const unsigned voff = 4u * (unsigned)(8 * half * p.Tx + ic);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    kv[s][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(krs, voff, 4u * (unsigned)((16 * s + jj) * p.Tx), 0));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                __bf16 hv, lv;
+                split_bf16(kv[s][jj], hv, lv);
+                ah[s][jj] = hv;
+                al[s][jj] = lv;
+            }
+        }
+    }
+    {
+        // |k_i|^2 and the bias: the compute waves wait for the loader's first strip here anyway
+        float nrm = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) nrm = fmaf(kv[k][jj], kv[k][jj], nrm);
+        float n0, n1;
+        rt_halves(nrm, n0, n1);
+        nrm = n0 + n1;
+        // per-row additive term of the base-2 logit: s2*|k_i|^2 (L2) or 0 (dot); -inf masks rows >= t_x.  Through LDS
+        // into the accumulator layout (rows (e&3) + 8*(e>>2) + 4*half): this wave's words only, no barrier
+        if (lane < 32) knl[tile * 32 + lane] = (row_i < tx) ? (l2 ? s2 * nrm : 0.f) : NEG_INF_F;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) bz[gq] = *reinterpret_cast<const float4 *>(knl + tile * 32 + 8 * gq + 4 * half);
+    }
+    RT_STAMP(1);
+    rt_barrier();                                     // barrier A: strip 0 is in the ring
+
+    bf16x8 bh[KS], bl[KS];
+    auto read_b = [&](int s) {
+        const uint4 *F = reinterpret_cast<const uint4 *>(frg + (s % RT_RING) * SLOTB) + lane;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            bh[k] = __builtin_bit_cast(bf16x8, F[(2 * k) * 64]);
+            bl[k] = __builtin_bit_cast(bf16x8, F[(2 * k + 1) * 64]);
+        }
+    };
+    // the utterance's [Tx,Ty] block as a buffer resource: stores to rows >= Tx of the last tile are dropped by the
+    // hardware, a lane whose frame does not exist carries an offset beyond any block (softattn_kernel's store path)
+    constexpr unsigned esz = OUT16 ? 2u : 4u;
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<unsigned char *>(p.logp) + (size_t)b * p.Tx * p.Ty * esz, 0, (unsigned)p.Tx * (unsigned)p.Ty * esz,
+        0x00020000);
+    const unsigned row_bytes = (unsigned)p.Ty * esz;
+    const unsigned tile_bytes = (unsigned)(32 * tile) * row_bytes;
+    auto lane_byte_of = [&](int j) {
+        const int col = f0 + 32 * j + l31;
+        return col < p.Ty ? (unsigned)(4 * half * p.Ty + col) * esz : 0x80000000u;
+    };
+    auto out_store = [&](float v, unsigned lane_byte, int e) {
+        const int iu = (e & 3) + 8 * (e >> 2);
+        if (!OUT16) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), out_rs, lane_byte, tile_bytes + (unsigned)iu * row_bytes, RT_ST_AUX);
+        } else {
+            const __bf16 hv = (__bf16)v;
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, hv), out_rs, lane_byte,
+                                                  tile_bytes + (unsigned)iu * row_bytes, RT_ST_AUX);
+        }
+    };
+
+    f32x16 acc;
+    {
+        read_b(0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k], bh[k], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k], bl[k], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k], bh[k], acc, 0, 0, 0);
+        }
+    }
+    rt_barrier();                                     // barrier B (= -1): strip 1 is in the ring
+    RT_STAMP(2);
+    // Strip j's iteration (between barriers j-1 and j) carries three strips: the MFMAs of strip j+1, the softmax
+    // statistics of strip j (logits from the accumulators of the previous iteration's MFMAs) and the STORES of strip
+    // j-1, whose normaliser the statistics published before barrier j-1 give.  The issue order is written out, one
+    // MFMA per slot with a slice of the vector work and at most two stores behind it (a wave whose stores and
+    // arithmetic alternate in phases leaves the CU's store path idle two thirds of the time: 4 k cycles a strip).
+    // lgP / lgC: base-2 logits (up to the frame's constant) of strip j-1 / j; the two arrays swap roles from one
+    // iteration to the next (the loop is unrolled by two: no copies).
+    constexpr int NSL = 3 * KS;                       // MFMA slots of a strip
+    constexpr int SS0 = 4;                            // first slot with a store of strip j-1 (the loader needs ~400 cycles for its constant)
+    unsigned lane_byteP = 0x80000000u;                // strip j-1's lane offsets (no strip -1: the stores are dropped)
+    // strip s's constant -lse*ln2 from the loader (c0buf), `first` = an earlier read of the word.  Polled a few times; a
+    // loader that is late (or a reader that is early) costs the merge this wave would otherwise have done itself --
+    // never a hang: the statistics are in LDS for every wave
+    auto frame_constant = [&](int s, unsigned first) -> float {
+        const volatile rt_lds_u32 *cp = (const volatile rt_lds_u32 *)(c0buf + (s & 1) * 32 + l31);
+        unsigned cv = first;
+        for (int t = 0; t < 8 && __builtin_amdgcn_ballot_w64(cv == RT_PENDING) != 0; ++t) cv = *cp;
+        if (__builtin_amdgcn_ballot_w64(cv == RT_PENDING) != 0) {
+            float2 st[NT];
+#pragma unroll
+            for (int w = 0; w < NT; ++w) st[w] = stat[((s & 1) * NT + w) * 32 + l31];
+            return rt_merge<NT>(st);
+        }
+        return __builtin_bit_cast(float, cv);
+    };
+    auto body = [&](int j, float (&lgP)[16], float (&lgC)[16], auto more_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_tag)::value;      // strip j+1 exists: its MFMAs run here
+        constexpr bool FIRST = decltype(first_tag)::value;    // strip 0: there is no strip -1 to store
+        // ---- LDS reads first: strip j-1's constant (if it is there already), strip j+1's B fragments
+        unsigned cfirst = RT_PENDING;
+        if (!FIRST) cfirst = *(const volatile rt_lds_u32 *)(c0buf + ((j + 1) & 1) * 32 + l31);
+        if (MORE) read_b(j + 1);
+        // ---- strip j: logits and their maximum
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            lgC[4 * gq + 0] = fmaf(acc[4 * gq + 0], dmul, bz[gq].x);
+            lgC[4 * gq + 1] = fmaf(acc[4 * gq + 1], dmul, bz[gq].y);
+            lgC[4 * gq + 2] = fmaf(acc[4 * gq + 2], dmul, bz[gq].z);
+            lgC[4 * gq + 3] = fmaf(acc[4 * gq + 3], dmul, bz[gq].w);
+        }
+        float tmax = fmaxf(fmaxf(lgC[0], lgC[1]), lgC[2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) tmax = fmaxf(fmaxf(tmax, lgC[e]), lgC[e + 1]);
+        tmax = fmaxf(tmax, lgC[15]);
+        float t0, t1;
+        rt_halves(tmax, t0, t1);
+        tmax = fmaxf(t0, t1);
+        const float ms = (tmax == NEG_INF_F) ? 0.f : tmax;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the slots
+        float c0P = 0.f, ls = 0.f, xe = 0.f;
+        bool have_xe = false;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            if (MORE) {
+                const int s3 = k / 3, q3 = k % 3;
+                if (k == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh[0], z, 0, 0, 0);
+                } else if (q3 == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s3], bh[s3], acc, 0, 0, 0);
+                else if (q3 == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s3], bl[s3], acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s3], bh[s3], acc, 0, 0, 0);
+            }
+            if (!FIRST && k == SS0) c0P = frame_constant(j - 1, cfirst);
+            // stores of strip j-1
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!FIRST && SS0 + e * (NSL - SS0) / 16 == k) out_store(fmaf(lgP[e], LN2_F, c0P), lane_byteP, e);
+            // strip j: 2^(x - max), each sum one slot behind its exp (no transcendental waited for)
+            if (have_xe) { ls += xe; have_xe = false; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (e * NSL / 16 == k) {
+                    const float x = __builtin_amdgcn_exp2f(lgC[e] - ms);
+                    xe = have_xe ? xe + x : x;
+                    have_xe = true;
+                }
+            asm volatile("" : "+v"(ls), "+v"(xe));    // keep the slice here (the IR sink pass would move it)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (have_xe) ls += xe;
+        rt_halves(ls, t0, t1);
+        ls = t0 + t1;
+        if (lane < 32) stat[((j & 1) * NT + tile) * 32 + lane] = make_float2(tmax, ls);
+        lane_byteP = lane_byte_of(j);
+        RT_STAMP(8 + 4 * j);
+        rt_barrier();
+        RT_STAMP(9 + 4 * j);
+    };
+    // the last strip's stores
+    auto finish = [&](float (&lgP)[16]) __attribute__((always_inline)) {
+        const unsigned cfirst = *(const volatile rt_lds_u32 *)(c0buf + ((NS - 1) & 1) * 32 + l31);
+        const float c0 = frame_constant(NS - 1, cfirst);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out_store(fmaf(lgP[e], LN2_F, c0), lane_byteP, e);
+    };
+    float lgA[16], lgB[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lgA[e] = 0.f;
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    if (NS == 1) {
+        body(0, lgA, lgB, F, T);
+        finish(lgB);
+    } else {
+        body(0, lgA, lgB, T, T);
+        int j = 1;
+        for (; j + 2 < NS; j += 2) {
+            body(j, lgB, lgA, T, F);
+            body(j + 1, lgA, lgB, T, F);
+        }
+        if (j + 1 < NS) {
+            body(j, lgB, lgA, T, F);
+            body(j + 1, lgA, lgB, F, F);
+            finish(lgB);
+        } else {
+            body(j, lgB, lgA, F, F);
+            finish(lgA);
+        }
+    }
+    RT_STAMP(5);
+    if (p.stamps) {                       // debug only: when have this wave's stores left the CU?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RT_STAMP(6);
+        if (lane == 0) p.stamps[((size_t)blockIdx.x * (NT + 1) + wave) * 64 + 4] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1497,6 +1996,19 @@ static int launch_softattn(const SoftAttnParams &p, unsigned char *ws, const SaL
     return ALIGNER_OK;
 }
 
+// row-tile form: one compute wave per 32-row tile + the loader wave; 256 frames per workgroup
+template <int KS, int NT, bool OUT16>
+static int launch_softattn_rt(const SoftAttnParams &p, hipStream_t s) {
+    const size_t lds = (size_t)(rt_raw_slots(KS) + RT_RING) * KS * 2048 + (size_t)2 * NT * 32 * sizeof(float2) + (size_t)(NT + 2) * 32 * sizeof(float);
+    static_assert(((rt_raw_slots(KS) + RT_RING) * KS * 2048 + 2 * NT * 32 * 8 + (NT + 2) * 32 * 4) <= 160 * 1024, "LDS");
+    auto kern = softattn_rt_kernel<KS, NT, OUT16>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    dim3 grid((unsigned)((p.Ty + 32 * RT_STRIPS - 1) / (32 * RT_STRIPS)) * (unsigned)p.B), block((NT + 1) * 64);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
+
 template <int KS>
 static int launch_softattn_exact(const SoftAttnParams &p, hipStream_t s) {
     const size_t per_tile = (size_t)8 * KS * 64 * sizeof(float);
@@ -1563,6 +2075,13 @@ int aligner_softattn(const float *keys, const float *queries, const int32_t *t_x
     const bool multi = L.RT > G;
     if (soft_out && prior && multi)
         return fail(ALIGNER_EDOM, "soft output with a prior needs Tx <= %d", 32 * G);
+    // the row-tile form (softattn_rt_kernel): one row group, no channel padding (the loader's LDS-DMA reads whole
+    // 8-channel pieces), frames in aligned quads, log-probs only
+    if (!multi && L.KS <= 8 && C == 16 * L.KS && (Ty & 3) == 0 && !prior && !soft_out && !g_opt_softattn_strips &&
+        (reinterpret_cast<uintptr_t>(queries) & 15) == 0) {
+        if (L.KS == 5) return p.out16 ? launch_softattn_rt<5, 7, true>(p, s) : launch_softattn_rt<5, 7, false>(p, s);
+        return p.out16 ? launch_softattn_rt<8, 7, true>(p, s) : launch_softattn_rt<8, 7, false>(p, s);
+    }
     if (L.KS == 5) return multi ? launch_softattn<5, 7, true>(p, ws, L, s) : launch_softattn<5, 7, false>(p, ws, L, s);
     if (L.KS == 8) return multi ? launch_softattn<8, 7, true>(p, ws, L, s) : launch_softattn<8, 7, false>(p, ws, L, s);
     return multi ? launch_softattn<16, 4, true>(p, ws, L, s) : launch_softattn<16, 4, false>(p, ws, L, s);
