@@ -30,6 +30,7 @@ int g_opt_mobo_start_lag = 0;
 int g_opt_mobo_lanes = 0;
 int g_opt_mobo_bwd_general = 0;
 int g_opt_softattn_no_pair = 0;
+int g_opt_softattn_rt_drop_merge = 0;
 int g_opt_softattn_strips = env_flag("ALIGNER_SOFTATTN_STRIPS");
 int g_opt_softattn_split = 0;
 int g_opt_conv_narrow_ft = 0;
@@ -123,6 +124,7 @@ int aligner_debug_set_option(const char *name, int value) {
     if (std::strcmp(name, "conv_split_always") == 0) { aligner::g_opt_conv_split_always = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_split_walk") == 0) { aligner::g_opt_maxpath_no_split_walk = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_strips") == 0) { aligner::g_opt_softattn_strips = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "softattn_rt_drop_merge") == 0) { aligner::g_opt_softattn_rt_drop_merge = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_no_pair") == 0) { aligner::g_opt_softattn_no_pair = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_bwd_general") == 0) { aligner::g_opt_mobo_bwd_general = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_drop_segment") == 0) { aligner::g_opt_mobo_drop_segment = value; return ALIGNER_OK; }

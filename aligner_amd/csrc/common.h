@@ -53,6 +53,7 @@ extern int g_opt_conv_no_fuse;        // "conv_no_fuse": testing / A-B, a stack'
 extern int g_opt_conv_split_always;    // "conv_split_always": narrow layers never stage fp32 themselves (A/B, tests)
 extern int g_opt_softattn_split;       // "softattn_split": development, waves per strip of the row-group form (2, 4; 1: at most 2; 0: the launch's choice)
 extern int g_opt_softattn_strips;      // "softattn_strips": A/B / testing, the one-row-group similarity kernel in its strip-per-wave form (softattn_kernel) instead of the row-tile form
+extern int g_opt_softattn_rt_drop_merge;   // "softattn_rt_drop_merge": testing, the row-tile similarity kernel's loader never publishes a strip's normaliser
 extern int g_opt_softattn_no_pair;     // "softattn_no_pair": testing, the similarity kernel's row-group form with one wave per strip only
 extern int g_opt_mobo_bwd_general;     // "mobo_bwd_general": testing, the gradient's chain in its general (one exp2 per term) form
 extern int g_opt_mobo_lanes;           // "mobo_lanes": development, lanes per position in the split form (0: the plan's choice)

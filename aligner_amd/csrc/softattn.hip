@@ -924,6 +924,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         // the NT tiles' statistics of strip s merged into the frame's constant -lse*ln2 (what the compute waves add
         // to ln2 * logit): every wave needs it, one wave works it out
         auto merge = [&](int s) {
+            if (p.pair < 0) return;                   // testing ("softattn_rt_drop_merge"): every compute wave falls back to its own merge
             float2 st[NT];
 #pragma unroll
             for (int w = 0; w < NT; ++w) st[w] = stat[((s & 1) * NT + w) * 32 + l31];
@@ -1063,6 +1064,11 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
             bl[k] = __builtin_bit_cast(bf16x8, F[(2 * k + 1) * 64]);
         }
     };
+    auto read_bk = [&](int s, int k) {                // one k-step of strip s
+        const uint4 *F = reinterpret_cast<const uint4 *>(frg + (s % RT_RING) * SLOTB) + lane;
+        bh[k] = __builtin_bit_cast(bf16x8, F[(2 * k) * 64]);
+        bl[k] = __builtin_bit_cast(bf16x8, F[(2 * k + 1) * 64]);
+    };
     // the utterance's [Tx,Ty] block as a buffer resource: stores to rows >= Tx of the last tile are dropped by the
     // hardware, a lane whose frame does not exist carries an offset beyond any block (softattn_kernel's store path)
     constexpr unsigned esz = OUT16 ? 2u : 4u;
@@ -1131,7 +1137,8 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         // ---- LDS reads first: strip j-1's constant (if it is there already), strip j+1's B fragments
         unsigned cfirst = RT_PENDING;
         if (!FIRST) cfirst = *(const volatile rt_lds_u32 *)(c0buf + ((j + 1) & 1) * 32 + l31);
-        if (MORE) read_b(j + 1);
+        if (MORE) read_bk(j + 1, 0);                  // (the other k-steps' fragments one k-step ahead of their MFMAs: seven waves' reads
+                                                      // of a whole strip at once are 70 KB the LDS serves for ~500 cycles behind the barrier)
         // ---- strip j: logits and their maximum
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -1148,6 +1155,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         rt_halves(tmax, t0, t1);
         tmax = fmaxf(t0, t1);
         const float ms = (tmax == NEG_INF_F) ? 0.f : tmax;
+        RT_STAMP(10 + 4 * j);
         __builtin_amdgcn_sched_barrier(0);
         // ---- the slots
         float c0P = 0.f, ls = 0.f, xe = 0.f;
@@ -1156,6 +1164,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         for (int k = 0; k < NSL; ++k) {
             if (MORE) {
                 const int s3 = k / 3, q3 = k % 3;
+                if (q3 == 0 && s3 + 1 < KS) read_bk(j + 1, s3 + 1);
                 if (k == 0) {
                     f32x16 z;
 #pragma unroll
@@ -1182,6 +1191,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
             asm volatile("" : "+v"(ls), "+v"(xe));    // keep the slice here (the IR sink pass would move it)
             __builtin_amdgcn_sched_barrier(0);
         }
+        RT_STAMP(11 + 4 * j);
         if (have_xe) ls += xe;
         rt_halves(ls, t0, t1);
         ls = t0 + t1;
@@ -2002,9 +2012,11 @@ static int launch_softattn_rt(const SoftAttnParams &p, hipStream_t s) {
     const size_t lds = (size_t)(rt_raw_slots(KS) + RT_RING) * KS * 2048 + (size_t)2 * NT * 32 * sizeof(float2) + (size_t)(NT + 2) * 32 * sizeof(float);
     static_assert(((rt_raw_slots(KS) + RT_RING) * KS * 2048 + 2 * NT * 32 * 8 + (NT + 2) * 32 * 4) <= 160 * 1024, "LDS");
     auto kern = softattn_rt_kernel<KS, NT, OUT16>;
+    SoftAttnParams q = p;
+    q.pair = g_opt_softattn_rt_drop_merge ? -1 : 0;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
     dim3 grid((unsigned)((p.Ty + 32 * RT_STRIPS - 1) / (32 * RT_STRIPS)) * (unsigned)p.B), block((NT + 1) * 64);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, p);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, q);
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }

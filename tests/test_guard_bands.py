@@ -127,7 +127,9 @@ def test_zero_and_scatter_writes_stay_inside_their_buffers(dev, B, Tx, Ty, pdt, 
 
 
 @pytest.mark.parametrize("B,C,Tx,Ty", [(2, 80, 50, 130), (3, 80, 200, 1000), (1, 16, 33, 65), (2, 80, 257, 300),
-                                       (1, 80, 500, 1030)])
+                                       (1, 80, 500, 1030),
+                                       # the row-tile form (frames in quads, C = 16 KS): a partial strip, one frame quad, KS = 8
+                                       (3, 80, 199, 36), (2, 80, 224, 4), (2, 128, 100, 260)])
 @pytest.mark.parametrize("logp_dt", [_lib.DT_F32, _lib.DT_BF16])
 def test_similarity_writes_stay_inside_their_buffers(dev, B, C, Tx, Ty, logp_dt):
     lib = _lib.load()

@@ -128,6 +128,79 @@ def test_exact_product_kernel_matches_oracle(dev, request, B, C, Tx, Ty, sim):
         assert (soft.cpu() - want_soft).abs().max().item() < TOL
 
 
+# Row-tile form of the similarity kernel (softattn_rt_kernel: one row group, C = 80 or 128, frames in quads, log-probs
+# only): every structural case of it -- one strip, a partial last strip, a partial last workgroup, text that leaves whole
+# row tiles masked, batches the XCD-aware map does and does not apply to, both k-step counts, both similarities.
+RT_SHAPES = [(1, 80, 200, 4, "l2"), (2, 80, 7, 32, "l2"), (3, 80, 224, 36, "dot"), (2, 80, 33, 64, "l2"),
+             (5, 80, 200, 260, "l2"), (8, 80, 129, 512, "l2"), (2, 128, 224, 300, "l2"), (16, 128, 64, 96, "dot"),
+             (3, 128, 1, 1000, "l2"), (9, 80, 100, 772, "l2")]
+
+
+@pytest.mark.parametrize("B,C,Tx,Ty,sim", RT_SHAPES)
+def test_row_tile_form(dev, request, B, C, Tx, Ty, sim):
+    """Against the oracle at 1e-4 and against the strip-per-wave kernel (debug option `softattn_strips`: the same logits,
+    the log-sum-exp combined in another order); bf16 log-probs = the fp32 ones rounded to nearest even, bit for bit."""
+    import aligner_amd
+    from aligner_amd import _lib
+    from oracle import softattn_oracle as S
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 131 + Tx * 7 + Ty)
+    k = torch.randn(B, C, Tx, generator=g)
+    q = torch.randn(B, C, Ty, generator=g)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32)
+    t_x[0] = Tx
+    if B > 1:
+        t_x[1] = 1                                       # one valid row: six row tiles fully masked
+    temp = 0.0005 if sim == "l2" else 0.11
+    want, _ = S.soft_attention(k, q, t_x=t_x, temperature=temp, sim=sim)
+    kw = dict(t_x=t_x.to(dev), temperature=temp, sim=sim)
+    got, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
+    b16, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), logp_dtype=torch.bfloat16, **kw)
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"softattn_strips", 0))
+    assert lib.aligner_debug_set_option(b"softattn_strips", 1) == 0
+    strips, _ = aligner_amd.soft_attention(k.to(dev), q.to(dev), **kw)
+    lib.aligner_debug_set_option(b"softattn_strips", 0)
+    torch.cuda.synchronize()
+    assert _cmp(got, want) < TOL
+    fin = torch.isfinite(strips)
+    assert torch.equal(torch.isfinite(got), fin) and (got[fin] - strips[fin]).abs().max().item() < 2e-5
+    assert torch.equal(b16.cpu(), got.bfloat16().cpu())
+
+
+def test_row_tile_form_is_deterministic_under_uneven_load(dev, request):
+    """The compute waves take a strip's normaliser from the loader wave through LDS (polled, with their own merge of the
+    published statistics as the fall-back): both roads give the same bits, so the result must not depend on timing.
+    The bench shape again and again while a second stream keeps part of the chip busy with launches of other sizes."""
+    import aligner_amd
+    B, C, Tx, Ty = 64, 80, 200, 1000
+    g = torch.Generator().manual_seed(99)
+    k = torch.randn(B, C, Tx, generator=g).to(dev)
+    q = torch.randn(B, C, Ty, generator=g).to(dev)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32).to(dev)
+    ref, _ = aligner_amd.soft_attention(k, q, t_x=t_x)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    k2, q2 = k[:5, :, :70].contiguous(), q[:5, :, :388].contiguous()
+    outs = []
+    for it in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(1 + it % 3):
+                aligner_amd.soft_attention(k2, q2)
+        outs.append(aligner_amd.soft_attention(k, q, t_x=t_x)[0])
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o.view(torch.int32), ref.view(torch.int32))
+    # ... and with a loader that never publishes (every wave takes the fall-back, every strip)
+    from aligner_amd import _lib
+    lib = _lib.load()
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"softattn_rt_drop_merge", 0))
+    assert lib.aligner_debug_set_option(b"softattn_rt_drop_merge", 1) == 0
+    alone, _ = aligner_amd.soft_attention(k, q, t_x=t_x)
+    lib.aligner_debug_set_option(b"softattn_rt_drop_merge", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(alone.view(torch.int32), ref.view(torch.int32))
+
+
 def _oracle_per_utterance(k, q, t_x, **kw):
     """The oracle evaluated one utterance at a time (its [B,C,Tx,Ty] difference tensor is 4 GB at B = 64)."""
     from oracle import softattn_oracle as S

@@ -22,7 +22,7 @@ GRBM_GUI_ACTIVE is the sum over the 8 XCDs of the cycles the dispatch kept the c
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-KERNELS = ["softattn_kernel", "maxpath_pipelined_kernel", "expand_kernel", "conv_gemm_kernel", "conv1d_prepared_kernel",
+KERNELS = ["softattn_rt_kernel", "softattn_kernel", "maxpath_pipelined_kernel", "expand_kernel", "conv_gemm_kernel", "conv1d_prepared_kernel",
            "conv_split_kernel", "conv_narrow_fused_kernel", "conv_narrow_kernel", "mobo_chain_map_kernel"]
 
 

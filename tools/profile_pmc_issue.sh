@@ -9,7 +9,7 @@ python3 tools/pmc_issue.py $O/pmc_issue_counters.json "rocprofv3 --pmc (two pass
 python3 - <<PY
 import json
 d = json.load(open("$O/pmc_issue_counters.json"))["kernels"]
-for k in ("maxpath_pipelined_kernel", "softattn_kernel", "expand_kernel"):
+for k in ("maxpath_pipelined_kernel", "softattn_rt_kernel", "softattn_kernel", "expand_kernel"):
     v = d.get(k, {})
     print(k, {x: v.get(x) for x in ("SQ_WAVES", "kernel_cycles", "resident_waves", "wave_occupancy", "wait_any_share", "issue_stall_share", "valu_per_wave", "mfma_busy_share")})
 PY

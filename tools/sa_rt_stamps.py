@@ -59,12 +59,12 @@ end = np.sort((rt1.max(axis=1) - rt0.min()) / 100.0)
 print("workgroup drained times (us), deciles:", np.round(end[:: max(1, len(end) // 10)], 2))
 
 # per-strip stamps: 8+4j before barrier j, 9+4j after it, 10+4j statistics merged, 11+4j stores issued
-print("per strip (median cycles since entry): wave 1 | wave 5 | loader:  arrive at barrier / leave barrier")
+print("per strip (median cycles since entry): wave 1 | wave 5: logits + maximum done / slots done / arrive at barrier / leave | loader: arrive / leave")
 for j in range(8):
     def med(w, kk):
         v = s[:, w, kk]; ok = v > 0
         return np.median((v - t0)[ok]) if ok.any() else float("nan")
-    print(f"strip {j}: " + " | ".join(" ".join(f"{med(w, 8 + 4 * j + i):7.0f}" for i in range(2)) for w in (1, 5, 0)))
+    print(f"strip {j}: " + " | ".join(" ".join(f"{med(w, 8 + 4 * j + i):7.0f}" for i in ((2, 3, 0, 1) if w else (0, 1))) for w in (1, 5, 0)))
 
 def medl(kk):
     v = s[:, 0, kk]; ok = v > 0
