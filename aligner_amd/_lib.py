@@ -70,7 +70,6 @@ SIGNATURES = {
     "aligner_debug_set_stamps": (None, [_vp]),
     "aligner_debug_set_option": (_i, [_c.c_char_p, _i]),
     "aligner_maxpath_host_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _i]),
-    "aligner_fused_align_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _f, _vp]),
     "aligner_softattn_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_softattn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
     "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),

@@ -55,6 +55,7 @@ constexpr int RING_T   = 4;   // boundary ring depth in tiles
 constexpr int RING_LD  = 64;  // floats per ring slot: 32 used, padded so that all 64 lanes can store unmasked
 constexpr int RPW      = 63;  // text rows per compute wave (lane 0 is the ghost lane)
 constexpr int WS_HDR_BYTES = 256;
+constexpr int MV_CHUNKS = 32;  // mask_verify_kernel: pieces (row ranges) per utterance, one flag word each (eight pieces: 3.3 TB/s)
 
 enum Mode { MODE_NORMAL = 0, MODE_EMPTY = 1, MODE_COMPAT = 2 };
 
@@ -74,6 +75,7 @@ struct MaxpathParams {
     int         *dur;       // [B,Tx] nullable
     unsigned    *bits;      // [B,NT,ROWS] decision words in global memory
     int         *status;
+    const int   *mflag;     // MASKMODE 2: [B][MV_CHUNKS] nonzero = that piece of the utterance's mask is not all ones inside [0,t_x) x [0,t_y)
     int B, Tx, Ty, NT, ROWS;
     int WT;                 // tiles per backtrack window when the words live in global memory
     int bits_in_lds;        // pipelined kernel: decision words stay in LDS
@@ -89,7 +91,7 @@ struct MaxpathParams {
     unsigned    *xwalk;     // ... [B] the backtrack's hand-over from the second half to the first (0xFFFFFFFF until then)
     int          split_walk;    // ... each half walks its own rows out of its own LDS (its decision words all fit there)
     unsigned long long *stamps;   // debug: [B][16 waves][16] shader-clock stamps (nullable; [2B] when utterances are split)
-    float       *dump;      // fused kernel: [B][4 producers][64] words that swallow stores which must not happen
+    float       *dump;      // (the fused similarity -> search experiment's: tools/experiments/fused_align.patch) unused
     void        *path1;     // ALIGNER_F_PATH_PREZEROED: the caller's all-zero dense path; the kernel writes its ones (nullable)
     int          path1_es;  // ... element size in bytes (1, 2, 4, 8)
     unsigned long long path1_one;   // ... the bits of a 1 in that dtype
@@ -1368,6 +1370,16 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         __syncthreads();
         if (threadIdx.x == 0 && !(p.flags & ALIGNER_F_TEST_DROP_ZERO_REPORTS))                  // (testing: the zeros are written, never reported)
             __hip_atomic_fetch_add(p.zsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the workgroup says so
+    } else if (MASKMODE == 2) {
+        // strict mask, decided per utterance on the device: mask_verify_kernel found the mask all ones wherever the
+        // search reads a score (a 0/1 prefix rectangle, the usual x_mask * y_mask) -> value * mask IS value there and
+        // the mask stream is skipped; anything else takes the multiply (__init__.py:11).  Uniform, outside every loop.
+        const int blk = (int)blockIdx.x - Z;
+        const int b = PAIR ? (blk >= p.B ? blk - p.B : blk) : blk;
+        static_assert(MV_CHUNKS <= 64, "one flag word per lane");
+        const int mine = (threadIdx.x & 63) < MV_CHUNKS ? p.mflag[b * MV_CHUNKS + (threadIdx.x & 63)] : 0;
+        if (__builtin_amdgcn_ballot_w64(mine != 0) != 0) maxpath_pipelined_body<NW, DEPTH, VEC, 1, VT, PAIR>(p, blk);
+        else maxpath_pipelined_body<NW, DEPTH, VEC, 0, VT, PAIR>(p, blk);
     } else {
         maxpath_pipelined_body<NW, DEPTH, VEC, MASKMODE, VT, PAIR>(p, (int)blockIdx.x - Z);
     }
@@ -1384,8 +1396,6 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         }
     }
 }
-
-#include "fused_align.inc"
 
 // --------------------------------------------------------------------------
 // starts -> dense 0/1 path in the caller's dtype (the reference's return value,
@@ -1459,12 +1469,124 @@ __global__ __launch_bounds__(256) void lengths_kernel(const T *__restrict__ mask
     }
 }
 
+// Is `value * mask` (__init__.py:11) the identity on every score the search reads?  The search of a normal utterance
+// (1 <= t_x <= t_y) reads the cells [0,t_x) x [0,t_y) and nothing else, so it is when the mask holds a ONE
+// of its dtype in all of them -- which the usual x_mask[:, :, None] * y_mask[:, None, :] does.  One full-rate pass over
+// those cells; piece c of utterance b (a range of rows) leaves its verdict in flag[b][c] (a plain store: every word is
+// rewritten by every call, nothing to reset).  The verdict may err on the safe side only ("multiply"): a piece does
+// not know t_x (the strided column sum of __init__.py:18 is one round trip too many for 2048 workgroups: only piece
+// 0 takes it, for the search's lengths), it takes a row for inside the rectangle when the row's first element is
+// ONE and asks that column 0 over its rows (and the row before them) is ONES THEN ZEROS -- then "first element ONE" is
+// "x < t_x" and the test is exact; any other column 0 is flagged.  t_y is the reference's row sum.  Utterances in the
+// reference's degenerate modes (t_x > t_y walks raw scores outside the rectangle; empty ones) keep the multiply: piece 0
+// sees the lengths and says so.
+template <int ES, int VT>
+__global__ __launch_bounds__(256) void mask_verify_kernel(const void *__restrict__ maskv, int Tx, int Ty,
+                                                           const int *__restrict__ t_xs_in, const int *__restrict__ t_ys_in,
+                                                           int *__restrict__ t_xs_out, int *__restrict__ t_ys_out,
+                                                           int *__restrict__ flag, unsigned one_bits) {
+    __shared__ float red[2][4];
+    __shared__ int anybad;
+    typedef typename std::conditional<ES == 4, float, unsigned short>::type E;      // (mask_value's element types)
+    typedef typename std::conditional<ES == 4, unsigned, unsigned short>::type U;
+    constexpr int EPV = 16 / ES;                                     // elements per 16-byte load
+    constexpr int NQ = 4;                                            // 16-byte loads in flight per lane
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const E *m = static_cast<const E *>(maskv) + (size_t)b * Tx * Ty;
+    const U *mu = reinterpret_cast<const U *>(m);
+    const U one = (U)one_bits;
+    const unsigned w1 = ES == 4 ? one_bits : (one_bits | (one_bits << 16));
+    if (tid == 0) anybad = 0;
+    const bool given = t_xs_in != nullptr;
+    int tx = given ? t_xs_in[b] : -1, ty = given ? t_ys_in[b] : 0;
+    const int rows = given ? (tx < Tx ? (tx > 0 ? tx : 0) : Tx) : Tx;       // given lengths: rows [0, t_x) exactly
+    const int per = (rows + MV_CHUNKS - 1) / MV_CHUNKS;
+    const int r0 = c * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const bool vec = (Ty % EPV == 0) && ((reinterpret_cast<uintptr_t>(maskv) & 15) == 0);
+    const int nqrow = Ty / EPV;                                      // 16-byte pieces of a whole row
+    // One row of the piece per wave and round: its first NQ x 64 pieces are asked for BEFORE anything is known about
+    // the lengths (the loads' addresses do not depend on them) -- a piece is two dependent memory round trips
+    // (row sum -> t_y, rows), not five.
+    auto fetch = [&](int x, uint4 (&v)[NQ], U &before) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(mu + (size_t)x * Ty);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int q = lane + 64 * i;
+            v[i] = row[q < nqrow ? q : nqrow - 1];                  // (clamped: unconditional loads)
+        }
+        before = x > 0 ? mu[(size_t)(x - 1) * Ty] : one;
+    };
+    uint4 v[NQ];
+    U before = one;
+    int x = r0 + wave;
+    if (vec && x < r1) fetch(x, v, before);
+    if (!given) {
+        // t_y: the row sum (every piece: 4 KB, contiguous); t_x: the column sum (piece 0 only, for the search)
+        float sx = 0.f, sy = 0.f;
+        for (int y = tid; y < Ty; y += 256) sy += mask_value<E, VT>(m[y]);                      // mask[b, 0, y]
+        if (c == 0)
+            for (int xx = tid; xx < Tx; xx += 256) sx += mask_value<E, VT>(m[(size_t)xx * Ty]);   // mask[b, x, 0]
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sx += __shfl_down(sx, off);
+            sy += __shfl_down(sy, off);
+        }
+        if (lane == 0) { red[0][wave] = sx; red[1][wave] = sy; }
+    }
+    __syncthreads();
+    if (!given) {
+        ty = (int)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);                             // astype(np.int32),
+        if (c == 0) {                                                                           // summed as lengths_kernel does
+            tx = (int)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            if (tid == 0) { t_xs_out[b] = tx; t_ys_out[b] = ty; }
+        }
+    }
+    int bad = 0;
+    if (tx >= 0 && !(tx >= 1 && tx <= ty && tx <= Tx && ty <= Ty)) bad = 1;     // (who knows t_x) not the normal mode
+    if (ty < 1 || ty > Ty) bad = 1;
+    if (!bad) {
+        const int nq = vec ? ty / EPV : 0;                           // whole 16-byte pieces inside the row's valid part
+        for (; x < r1; x += 4) {                                     // a wave per row: coalesced 1 KB runs
+            bool inside = true;
+            if (vec) {
+                const unsigned f0 = __builtin_amdgcn_readfirstlane(v[0].x);     // the row's first element (s)
+                const U first = (U)(ES == 4 ? f0 : (f0 & 0xFFFFu));
+                if (!given) {
+                    // column 0 over the piece: ONE or zero, never a ONE behind a zero (the row before the piece included)
+                    bad |= (first != one && first != 0) | (first == one && before != one);
+                    inside = first == one;                           // (wave-uniform)
+                }
+                if (inside) {
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        if (lane + 64 * i < nq) bad |= (v[i].x != w1) | (v[i].y != w1) | (v[i].z != w1) | (v[i].w != w1);
+                    const uint4 *row = reinterpret_cast<const uint4 *>(mu + (size_t)x * Ty);
+                    for (int q = lane + 64 * NQ; q < nq; q += 64) {  // rows longer than NQ x 64 pieces
+                        const uint4 w = row[q];
+                        bad |= (w.x != w1) | (w.y != w1) | (w.z != w1) | (w.w != w1);
+                    }
+                }
+                if (x + 4 < r1) fetch(x + 4, v, before);
+            } else if (!given) {
+                const U first = mu[(size_t)x * Ty], bf = x > 0 ? mu[(size_t)(x - 1) * Ty] : one;
+                bad |= (first != one && first != 0) | (first == one && bf != one);
+                inside = first == one;
+            }
+            if (inside)
+                for (int y = nq * EPV + lane; y < ty; y += 64) bad |= mu[(size_t)x * Ty + y] != one;
+        }
+    }
+    if (bad) anybad = 1;
+    __syncthreads();
+    if (tid == 0) flag[b * MV_CHUNKS + c] = anybad;
+}
+
 // --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
 
 struct WsLayout {
-    size_t status_off, len_off, starts_off, bits_off, dump_off, xring_off, xring_bytes, total;
+    size_t status_off, len_off, mflag_off, starts_off, bits_off, dump_off, xring_off, xring_bytes, total;
     int NT, ROWS;
 };
 
@@ -1478,7 +1600,8 @@ static WsLayout ws_layout(int B, int Tx, int Ty) {
     L.ROWS = ((rows_pipe > rows_plain ? rows_pipe : rows_plain) + 63) / 64 * 64;
     L.status_off = 0;
     L.len_off = WS_HDR_BYTES;
-    L.starts_off = align_up(L.len_off + (size_t)2 * B * sizeof(int), 256);
+    L.mflag_off = L.len_off + (size_t)2 * B * sizeof(int);          // [B][MV_CHUNKS] mask_verify_kernel's verdicts
+    L.starts_off = align_up(L.mflag_off + (size_t)B * MV_CHUNKS * sizeof(int), 256);
     L.bits_off = align_up(L.starts_off + (size_t)B * (Tx + 1) * sizeof(int), 256);
     L.dump_off = align_up(L.bits_off + (size_t)B * L.NT * L.ROWS * sizeof(unsigned), 256);
     // two workgroups per utterance: the boundary row between them, 32 words per tile, and a done word (PAIR)
@@ -1511,6 +1634,13 @@ static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStrea
     return ALIGNER_OK;
 }
 
+template <int NW, int DEPTH, bool VEC, int VT>
+static int launch_pipelined_mm(MaxpathParams p, int maskmode, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 0, VT>, grid, block, lds, s, p);
+    if (maskmode == 2) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 2, VT>, grid, block, lds, s, p);
+    return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 1, VT>, grid, block, lds, s, p);
+}
+
 template <int NW, int DEPTH>
 static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, size_t lds, hipStream_t s) {
     dim3 grid(p.B + p.zero_blocks), block(NW * 128);
@@ -1518,21 +1648,13 @@ static int launch_pipelined(MaxpathParams p, bool vec, int maskmode, int vt, siz
         // 16-bit scores: 16-byte loaders only (the caller routes everything else to the generic kernel),
         // and only the two wide workgroup shapes are built (narrow text runs on NW = 4 with idle waves)
         if (NW >= 4) {
-            if (vt == VT_BF16) {
-                if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 0, VT_BF16>, grid, block, lds, s, p);
-                return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 1, VT_BF16>, grid, block, lds, s, p);
-            }
-            if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 0, VT_F16>, grid, block, lds, s, p);
-            return launch_with_lds(maxpath_pipelined_kernel<(NW >= 4 ? NW : 4), DEPTH, true, 1, VT_F16>, grid, block, lds, s, p);
+            if (vt == VT_BF16) return launch_pipelined_mm<(NW >= 4 ? NW : 4), DEPTH, true, VT_BF16>(p, maskmode, grid, block, lds, s);
+            return launch_pipelined_mm<(NW >= 4 ? NW : 4), DEPTH, true, VT_F16>(p, maskmode, grid, block, lds, s);
         }
         return fail(ALIGNER_EINVAL, "internal: 16-bit scores on a narrow workgroup");
     }
-    if (vec) {
-        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 0, VT_F32>, grid, block, lds, s, p);
-        return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, true, 1, VT_F32>, grid, block, lds, s, p);
-    }
-    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 0, VT_F32>, grid, block, lds, s, p);
-    return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, false, 1, VT_F32>, grid, block, lds, s, p);
+    if (vec) return launch_pipelined_mm<NW, DEPTH, true, VT_F32>(p, maskmode, grid, block, lds, s);
+    return launch_pipelined_mm<NW, DEPTH, false, VT_F32>(p, maskmode, grid, block, lds, s);
 }
 
 __global__ __launch_bounds__(256) void xring_fill_kernel(uint4 *dst, int n16) {
@@ -1541,18 +1663,17 @@ __global__ __launch_bounds__(256) void xring_fill_kernel(uint4 *dst, int n16) {
 }
 
 // two workgroups per utterance (grid 2B), 16-byte loaders only
+template <int VT>
+static int launch_pair_mm(MaxpathParams p, int maskmode, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT, true>, grid, block, lds, s, p);
+    if (maskmode == 2) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 2, VT, true>, grid, block, lds, s, p);
+    return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT, true>, grid, block, lds, s, p);
+}
 static int launch_pair(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
     dim3 grid(2 * p.B + p.zero_blocks), block(4 * 128);
-    if (vt == VT_BF16) {
-        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_BF16, true>, grid, block, lds, s, p);
-        return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_BF16, true>, grid, block, lds, s, p);
-    }
-    if (vt == VT_F16) {
-        if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_F16, true>, grid, block, lds, s, p);
-        return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_F16, true>, grid, block, lds, s, p);
-    }
-    if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT_F32, true>, grid, block, lds, s, p);
-    return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT_F32, true>, grid, block, lds, s, p);
+    if (vt == VT_BF16) return launch_pair_mm<VT_BF16>(p, maskmode, grid, block, lds, s);
+    if (vt == VT_F16) return launch_pair_mm<VT_F16>(p, maskmode, grid, block, lds, s);
+    return launch_pair_mm<VT_F32>(p, maskmode, grid, block, lds, s);
 }
 
 template <int R, int VT>
@@ -1609,7 +1730,28 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
     unsigned char *wsb = static_cast<unsigned char *>(ws);
 
-    if (!t_xs || !t_ys) {
+    // Strict mask on the kernels that can decide per utterance (the pipelined forms): one pass over the mask's
+    // rectangle verifies that the multiply is the identity there (and derives the lengths on the way), and the search
+    // then skips the mask stream (MASKMODE 2)
+    const bool dyn_mask = (flags & ALIGNER_F_STRICT_MASK) && !(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_WRITE_Q)) &&
+                          !g_opt_maxpath_no_mask_verify;
+    if (dyn_mask) {
+        int *lx = reinterpret_cast<int *>(wsb + L.len_off), *ly = lx + B;
+        int *mf = reinterpret_cast<int *>(wsb + L.mflag_off);
+        const bool derive = !t_xs || !t_ys;
+        dim3 grid(MV_CHUNKS, B), block(256);
+        if (vt == VT_F32)
+            hipLaunchKernelGGL((mask_verify_kernel<4, VT_F32>), grid, block, 0, s, mask, Tx, Ty, derive ? nullptr : t_xs,
+                               derive ? nullptr : t_ys, lx, ly, mf, 0x3F800000u);
+        else if (vt == VT_BF16)
+            hipLaunchKernelGGL((mask_verify_kernel<2, VT_BF16>), grid, block, 0, s, mask, Tx, Ty, derive ? nullptr : t_xs,
+                               derive ? nullptr : t_ys, lx, ly, mf, 0x3F80u);
+        else
+            hipLaunchKernelGGL((mask_verify_kernel<2, VT_F16>), grid, block, 0, s, mask, Tx, Ty, derive ? nullptr : t_xs,
+                               derive ? nullptr : t_ys, lx, ly, mf, 0x3C00u);
+        ALIGNER_HIP_CHECK(hipGetLastError());
+        if (derive) { t_xs = lx; t_ys = ly; }
+    } else if (!t_xs || !t_ys) {
         int *lx = reinterpret_cast<int *>(wsb + L.len_off), *ly = lx + B;
         int rc = aligner_lengths_from_mask(mask, mask_dtype, B, Tx, Ty, lx, ly, s);
         if (rc) return rc;
@@ -1625,6 +1767,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.dur = dur_out;
     p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
     p.status = reinterpret_cast<int *>(wsb + L.status_off);
+    p.mflag = reinterpret_cast<const int *>(wsb + L.mflag_off);
     p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
     p.neg = neg; p.flags = flags;
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0;
@@ -1649,6 +1792,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
         p.flags = flags;
     }
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
+    const int pipemask = dyn_mask ? 2 : maskmode;                       // the pipelined launches: decided per utterance on the device
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
     const int per16 = vt == VT_F32 ? 4 : 8;                      // scores per 16-byte load
@@ -1697,7 +1841,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                     if (path_done) *path_done = true;
                 }
             }
-            return launch_pair(p, maskmode, vt, lds, s);
+            return launch_pair(p, pipemask, vt, lds, s);
         }
     }
     if (!(flags & ALIGNER_F_FORCE_GENERIC) && nw_need <= 8 && (vt == VT_F32 || vec)) {
@@ -1738,10 +1882,10 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                     if (path_done) *path_done = true;
                 }
                 switch (NW) {
-                    case 1: return launch_pipelined<1, 4>(p, vec, maskmode, vt, lds, s);
-                    case 2: return launch_pipelined<2, 4>(p, vec, maskmode, vt, lds, s);
-                    case 4: return launch_pipelined<4, 2>(p, vec, maskmode, vt, lds, s);
-                    default: return launch_pipelined<8, 2>(p, vec, maskmode, vt, lds, s);
+                    case 1: return launch_pipelined<1, 4>(p, vec, pipemask, vt, lds, s);
+                    case 2: return launch_pipelined<2, 4>(p, vec, pipemask, vt, lds, s);
+                    case 4: return launch_pipelined<4, 2>(p, vec, pipemask, vt, lds, s);
+                    default: return launch_pipelined<8, 2>(p, vec, pipemask, vt, lds, s);
                 }
             }
         }
@@ -1991,51 +2135,6 @@ int aligner_maxpath_f32(const float *value, const void *mask, int mask_dtype, co
                         float max_neg_val, int flags, void *stream) {
     return aligner_maxpath(value, ALIGNER_DT_F32, mask, mask_dtype, t_xs, t_ys, path_out, path_dtype, tok_out, dur_out,
                            ws, ws_bytes, B, Tx, Ty, max_neg_val, flags, stream);
-}
-
-int aligner_fused_align_f32(const float *keys, const float *queries, const int32_t *t_xs, const int32_t *t_ys,
-                            float *logp_out, int32_t *tok_out, int32_t *dur_out, void *ws, size_t ws_bytes, int B,
-                            int C, int Tx, int Ty, float temperature, int sim, float max_neg_val, void *stream) {
-    if (!keys || !queries || !t_xs || !t_ys || !ws) return fail(ALIGNER_EINVAL, "null pointer");
-    if (B < 0 || C < 1 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d C=%d Tx=%d Ty=%d", B, C, Tx, Ty);
-    if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
-    if (C > 16 * FA_KS || Tx > RPW * FA_NW || Ty > 64 * TC)
-        return fail(ALIGNER_EDOM, "fused form: C <= %d, Tx <= %d, Ty <= %d (C=%d Tx=%d Ty=%d)", 16 * FA_KS, RPW * FA_NW,
-                    64 * TC, C, Tx, Ty);
-    if (!(max_neg_val - max_neg_val == 0.0f)) return fail(ALIGNER_EINVAL, "max_neg_val must be finite");
-    if (B == 0) return ALIGNER_OK;
-    const WsLayout L = ws_layout(B, Tx, Ty);
-    if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
-    unsigned char *wsb = static_cast<unsigned char *>(ws);
-    FusedParams fp;
-    fp.keys = keys; fp.queries = queries; fp.logp = logp_out; fp.C = C; fp.temperature = temperature; fp.sim = sim;
-    MaxpathParams &p = fp.mp;
-    p.value = nullptr; p.mask = nullptr;
-    p.t_xs = t_xs; p.t_ys = t_ys;
-    p.starts = reinterpret_cast<int *>(wsb + L.starts_off);
-    p.tok = tok_out; p.dur = dur_out;
-    p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
-    p.status = reinterpret_cast<int *>(wsb + L.status_off);
-    p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
-    p.neg = max_neg_val; p.flags = 0;
-    p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0; p.force_exact = 0;
-    p.stamps = g_debug_stamps;
-    p.dump = reinterpret_cast<float *>(wsb + L.dump_off);
-    p.qout = nullptr;
-    p.path1 = nullptr; p.path1_es = 0; p.path1_one = 0;
-    p.xring = nullptr; p.xflag = nullptr; p.xwalk = nullptr; p.split_walk = 0;
-    const size_t lds_max = (size_t)lds_limit();
-    const FusedLds FL = fused_lds_layout();
-    p.WT = pick_window(L.NT, L.ROWS, Tx, lds_max);
-    if (p.WT <= 0) return fail(ALIGNER_EDOM, "Tx=%d/Ty=%d too large for the backtrack window", Tx, Ty);
-    size_t lds = walk_bytes(p.WT, L.ROWS, Tx);
-    if (lds < (size_t)FL.total) lds = FL.total;
-    if (lds > lds_max) return fail(ALIGNER_EDOM, "fused form needs %zu bytes of LDS (limit %zu)", lds, lds_max);
-    p.lds_total = (int)lds;
-    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(fused_align_kernel), lds));
-    hipLaunchKernelGGL(fused_align_kernel, dim3(B), dim3(FA_NW * 128), lds, static_cast<hipStream_t>(stream), fp);
-    ALIGNER_HIP_CHECK(hipGetLastError());
-    return ALIGNER_OK;
 }
 
 int aligner_maxpath_read_status(void *ws, int32_t *status_host, void *stream) {

@@ -203,6 +203,47 @@ def read_status(device=None) -> int:
     return st
 
 
+_ws_bytes: dict = {}            # (B, Tx, Ty) -> aligner_maxpath_workspace_bytes
+
+
+def _maximum_path_resident(value: torch.Tensor, mask: torch.Tensor, mask_is_prefix: bool) -> torch.Tensor:
+    """maximum_path() for what a training step passes: two contiguous GPU tensors of one floating dtype the kernels
+    read as it is.  One C-ABI call (the mask is verified / multiplied on the device, the lengths come from it, the dense
+    path is written by the search launch) and nothing else on the host: no promotion logic, no copies, no per-call
+    driver queries."""
+    device = value.device
+    B, Tx, Ty = value.shape
+    path = torch.empty((B, Tx, Ty), dtype=value.dtype, device=device)
+    if B == 0 or Tx == 0 or Ty == 0:
+        return path
+    lib = _lib.load()
+    other = torch.cuda.current_device() != device.index
+    if other:
+        prev = torch.cuda.current_device()
+        torch.cuda.set_device(device)
+    try:
+        nbytes = _ws_bytes.get((B, Tx, Ty))
+        if nbytes is None:
+            nbytes = _ws_bytes[(B, Tx, Ty)] = lib.aligner_maxpath_workspace_bytes(B, Tx, Ty)
+        ws = _workspaces.get(device, nbytes)
+        dt = _TORCH_TO_DT[value.dtype]
+        rc = lib.aligner_maxpath(value.data_ptr(), dt, mask.data_ptr(), dt, None, None, path.data_ptr(), dt, None, None,
+                                 ws.data_ptr(), ws.numel(), B, Tx, Ty, -1e9,
+                                 (0 if mask_is_prefix else _lib.F_STRICT_MASK) | _lib.F_COMPAT_TXGTTY,
+                                 torch.cuda.current_stream(device).cuda_stream)
+        if rc:
+            _lib.check(rc)
+    finally:
+        if other:
+            torch.cuda.set_device(prev)
+    if _CHECK_DEFAULT:
+        st = _status_of(ws, device)
+        if st & _lib.ST_INTERNAL:
+            raise RuntimeError(f"aligner_amd: internal consistency check failed on {device} (status word {st}); "
+                               "the affected utterances were returned all-zero")
+    return path
+
+
 def maximum_path(value: torch.Tensor, mask: torch.Tensor, *, mask_is_prefix: bool = False) -> torch.Tensor:
     """Drop-in for the reference's maximum_path (monotonic_align/__init__.py:6-21).
 
@@ -219,6 +260,9 @@ def maximum_path(value: torch.Tensor, mask: torch.Tensor, *, mask_is_prefix: boo
     """
     if value.dim() != 3 or mask.dim() != 3:
         raise ValueError("Buffer has wrong number of dimensions (expected 3)")   # core.c:27882
+    if (value.is_cuda and value.dtype is mask.dtype and value.dtype in _SCORE_DTYPES and value.shape == mask.shape
+            and value.device == mask.device and value.is_contiguous() and mask.is_contiguous()):
+        return _maximum_path_resident(value, mask, mask_is_prefix)
     out_dtype = torch.result_type(value, mask)                                   # value * mask, :11
     if not out_dtype.is_floating_point:
         # the reference would multiply in an integer dtype and then cast to fp32

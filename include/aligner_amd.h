@@ -319,23 +319,6 @@ size_t aligner_conv_stack_workspace_bytes(const aligner_conv_layer *layers, int 
 int aligner_conv_stack_f32(const float *x_dev, const aligner_conv_layer *layers, int n_layers, float *y_dev,
                            void *workspace_dev, size_t workspace_bytes, int B, int T, void *stream);
 
-/*
- * Similarity -> log-softmax -> alignment search in ONE kernel (no reference
- * counterpart): the DP consumes the log-probabilities from LDS as the matrix cores produce them, logp is written
- * once (or not at all: logp_out_dev may be NULL) and never re-read.  Same inputs as aligner_softattn_f32 (no
- * prior) + the lengths; outputs as aligner_maxpath_forward (token starts in the workspace: aligner_maxpath_expand
- * gives the dense path).  The path is bit-identical to aligner_maxpath on the logp this call writes.
- * Limits: C <= 80, Tx <= 252, Ty <= 2048, finite encodings; ALIGNER_EDOM otherwise.  Workspace as aligner_maxpath.
- * EXPERIMENT, closed as "measured, loses": 126 us against 53 us for aligner_softattn_f32 + aligner_maxpath_forward_f32 at
- * [64,80,200,1000] (all of logp leaves through the B CUs the search runs on); kept for the measurement record only.
- */
-int aligner_fused_align_f32(const float *keys_dev, const float *queries_dev,
-                            const int32_t *t_xs_dev, const int32_t *t_ys_dev,
-                            float *logp_out_dev, int32_t *tok_out_dev, int32_t *dur_out_dev,
-                            void *workspace_dev, size_t workspace_bytes,
-                            int B, int C, int Tx, int Ty,
-                            float temperature, int sim, float max_neg_val, void *stream);
-
 /* ---- the callers either side of the path (build-defined specs) ---- */
 
 /*

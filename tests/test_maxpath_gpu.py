@@ -274,6 +274,56 @@ def test_strict_mask_and_wrapper_semantics(golden_dir, dev):
     assert r.device.type == "cpu" and np.array_equal(r.numpy().astype(np.int8), z["path_f32"])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Tx,Ty", [(5, 200, 1000), (3, 70, 263), (2, 300, 808), (9, 33, 132), (2, 500, 4000)])
+def test_strict_mask_verified_on_the_device(dev, request, dt, B, Tx, Ty):
+    """The drop-in's strict mask (value * mask, __init__.py:11) without the second stream where it is a no-op:
+    mask_verify_kernel checks, per utterance, that the mask is ONE on every score the search reads and the search then
+    skips it.  Prefix rectangles (ragged, garbage scores outside them), one utterance whose mask has a hole, one whose
+    rectangle holds a value that is not one, one in the reference's t_x > t_y mode: each against the multiply done in
+    torch + the oracle, and bit for bit against the kernels with the verification switched off."""
+    import aligner_amd
+    from aligner_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(B * 7 + Tx + Ty)
+    v = torch.from_numpy(rng.standard_normal((B, Tx, Ty)).astype(np.float32) * 3).to(dt)
+    ty = rng.integers(Tx, Ty + 1, B).astype(np.int32)
+    tx = np.array([rng.integers(1, Tx + 1) for _ in ty], np.int32)
+    tx[0], ty[0] = Tx, Ty
+    m = torch.from_numpy(synth.prefix_mask(tx, ty, Tx, Ty)).to(dt)
+    v = v + (1 - m) * 1e4                                        # garbage where the mask is zero: must not matter
+    cases = {"prefix": m.clone()}
+    holes = m.clone()
+    holes[B - 1, tx[B - 1] // 2, ty[B - 1] // 2] = 0             # a hole inside the last utterance's rectangle
+    cases["hole"] = holes
+    scaled = m.clone()
+    scaled[0, Tx - 1, Ty - 1] = 0.5                              # the first utterance's last cell is not one
+    cases["not one"] = scaled
+    if B > 1 and Tx > 4:
+        degen = m.clone()
+        degen[1] = 0
+        degen[1, :4, :2] = 1                                     # t_x = 4 > t_y = 2: the reference's raw-score walk
+        cases["t_x > t_y"] = degen
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 0))
+    for name, mask in cases.items():
+        got = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        assert lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 1) == 0
+        mul = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 0)
+        torch.cuda.synchronize()
+        assert got.dtype == dt and torch.equal(got, mul), name
+        if name != "t_x > t_y":
+            lx = mask[:, :, 0].float().sum(1).int().numpy()
+            ly = mask[:, 0, :].float().sum(1).int().numpy()
+            want = _oracle_path((v * mask).float().numpy(), lx, ly)
+            assert np.array_equal(got.float().cpu().numpy().astype(np.int32), want), name
+    # lengths given by the caller, the mask only multiplied in
+    r = aligner_amd.align(v.to(dev), torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev), mask=cases["hole"].to(dev),
+                          strict_mask=True, path_dtype=torch.int32)
+    want = _oracle_path((v * cases["hole"]).float().numpy(), tx, ty)
+    assert np.array_equal(r.path.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_sixteen_bit_scores_read_directly(appendix_a, dev, dt):
     """bf16 / fp16 scores go straight into the DP's loaders (no up-cast pass): same path as the fp32 up-cast.

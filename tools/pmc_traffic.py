@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 KERNELS = {"softattn_kernel": "softattn_kernel", "maxpath_pipelined_kernel": "maxpath_pipelined_kernel",
-           "expand_kernel": "expand_kernel", "fused_align_kernel": "fused_align_kernel",
+           "expand_kernel": "expand_kernel",
            "mobo_forward_kernel": "mobo_forward_kernel"}
 
 
