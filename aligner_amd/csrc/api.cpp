@@ -37,6 +37,7 @@ int g_opt_conv_narrow_ft = 0;
 int g_opt_conv_no_fuse = 0;
 int g_opt_conv_split_always = env_flag("ALIGNER_CONV_SPLIT_ALWAYS");
 int g_opt_maxpath_no_split_walk = 0;
+int g_opt_maxpath_zero_blocks = 0;
 int g_opt_maxpath_no_mask_verify = 0;
 int g_opt_mobo_full_chain = 0;
 int g_opt_mobo_stamp_wave = 0;
@@ -124,6 +125,7 @@ int aligner_debug_set_option(const char *name, int value) {
     if (std::strcmp(name, "conv_no_fuse") == 0) { aligner::g_opt_conv_no_fuse = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_split_always") == 0) { aligner::g_opt_conv_split_always = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_mask_verify") == 0) { aligner::g_opt_maxpath_no_mask_verify = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "maxpath_zero_blocks") == 0) { aligner::g_opt_maxpath_zero_blocks = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_split_walk") == 0) { aligner::g_opt_maxpath_no_split_walk = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_strips") == 0) { aligner::g_opt_softattn_strips = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_rt_drop_merge") == 0) { aligner::g_opt_softattn_rt_drop_merge = value; return ALIGNER_OK; }

@@ -1637,8 +1637,14 @@ static int launch_with_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStrea
 template <int NW, int DEPTH, bool VEC, int VT>
 static int launch_pipelined_mm(MaxpathParams p, int maskmode, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 0, VT>, grid, block, lds, s, p);
-    if (maskmode == 2) return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 2, VT>, grid, block, lds, s, p);
-    return launch_with_lds(maxpath_pipelined_kernel<NW, DEPTH, VEC, 1, VT>, grid, block, lds, s, p);
+    if (NW <= 4) {
+        constexpr int N4 = NW <= 4 ? NW : 4;
+        if (maskmode == 2) return launch_with_lds(maxpath_pipelined_kernel<N4, DEPTH, VEC, 2, VT>, grid, block, lds, s, p);
+        return launch_with_lds(maxpath_pipelined_kernel<N4, DEPTH, VEC, 1, VT>, grid, block, lds, s, p);
+    }
+    // eight waves (128 registers a lane) with the mask stream: one tile in flight per loader (with two the loaders' 2 x 2 x 16
+    // registers spilled: 30-41 VGPRs, 104-116 bytes of scratch a lane)
+    return launch_with_lds(maxpath_pipelined_kernel<NW, 1, VEC, 1, VT>, grid, block, lds, s, p);
 }
 
 template <int NW, int DEPTH>
@@ -1666,7 +1672,6 @@ __global__ __launch_bounds__(256) void xring_fill_kernel(uint4 *dst, int n16) {
 template <int VT>
 static int launch_pair_mm(MaxpathParams p, int maskmode, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
     if (maskmode == 0) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 0, VT, true>, grid, block, lds, s, p);
-    if (maskmode == 2) return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 2, VT, true>, grid, block, lds, s, p);
     return launch_with_lds(maxpath_pipelined_kernel<4, 2, true, 1, VT, true>, grid, block, lds, s, p);
 }
 static int launch_pair(MaxpathParams p, int maskmode, int vt, size_t lds, hipStream_t s) {
@@ -1733,8 +1738,10 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     // Strict mask on the kernels that can decide per utterance (the pipelined forms): one pass over the mask's
     // rectangle verifies that the multiply is the identity there (and derives the lengths on the way), and the search
     // then skips the mask stream (MASKMODE 2)
+    // (up to four waves of text rows: the eight-wave workgroup has 128 registers a lane and its strict form keeps one
+    // tile in flight instead of two to stay inside them; the two-workgroup form keeps the plain multiply)
     const bool dyn_mask = (flags & ALIGNER_F_STRICT_MASK) && !(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_WRITE_Q)) &&
-                          !g_opt_maxpath_no_mask_verify;
+                          (Tx + RPW - 1) / RPW <= 4 && !g_opt_maxpath_no_mask_verify;
     if (dyn_mask) {
         int *lx = reinterpret_cast<int *>(wsb + L.len_off), *ly = lx + B;
         int *mf = reinterpret_cast<int *>(wsb + L.mflag_off);
@@ -1834,7 +1841,12 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                 const size_t pbytes = path_out ? (size_t)B * Tx * Ty * dtype_size(path_dtype) : 0;
                 if (path_out && !path_is_zero && !(flags & ALIGNER_F_SEPARATE_EXPAND) && cus - 2 * B >= 32 &&
                     (reinterpret_cast<uintptr_t>(path_out) & 15) == 0 && pbytes % 16 == 0 && dtype_size(path_dtype) > 0) {
-                    p.zero_blocks = cus - 2 * B;
+                    // 48 zero workgroups, not one per idle CU: the zeros are not needed before the outputs (~90 us into the
+                    // launch), and 240 workgroups flooding the write path for the first 13 us kept the 16 searching
+                    // workgroups from priming their loaders.  [8,500,4000] bf16, int32 path, HIP events: 117.3 us with
+                    // all idle CUs, 113.6 us with any count from 16 to 128 (durations only: 110.0 us)
+                    p.zero_blocks = cus - 2 * B < 48 ? cus - 2 * B : 48;
+                    if (g_opt_maxpath_zero_blocks > 0 && g_opt_maxpath_zero_blocks <= cus - 2 * B) p.zero_blocks = g_opt_maxpath_zero_blocks;
                     p.zero_nt = (flags & ALIGNER_F_STREAM_PATH) ? 1 : 0;
                     p.zero_n16 = pbytes / 16;
                     set_path_ones(p, path_out, path_dtype);

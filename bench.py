@@ -36,6 +36,7 @@ from aligner_amd import _lib, synth  # noqa: E402
 
 B, C_ATT, TX, TY = 64, 80, 200, 1000
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+SIM_KERNEL = "softattn_rt_kernel"     # the similarity kernel configs[1] launches (csrc/softattn.hip: the row-tile form)
 
 
 class Step:
@@ -480,7 +481,7 @@ def run_c3(args, world: int):
         "text encoder conv 512->1024 k3 alone (split pass + conv_gemm_kernel, fp32 out)": (event_time_us(lambda: aligner_amd.softattn.conv1d(text, *params.key_proj[0], relu=True), it, dev), f1),
         "text encoder conv 1024->80 k1 alone (conv_narrow_kernel, fp32 input staged and split in the kernel)": (event_time_us(lambda: aligner_amd.softattn.conv1d(k1, *params.key_proj[1]), it, dev), 2.0 * Bc * Tx * 2 * Ct * Ca),
         "mel encoder, whole stack in one call (conv_narrow_fused_kernel: fp32 input staged and split in the kernel, the three layers in one kernel)": (event_time_us(lambda: aligner_amd.softattn.encode(mel, params.query_proj), it, dev), 2.0 * Bc * Ty * (Cm * 2 * Cm * 3 + 2 * Cm * Cm + Cm * Ca)),
-        "similarity + log-softmax (softattn_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx), it, dev), 2.0 * Bc * Tx * Ty * Ca),
+        "similarity + log-softmax (softattn_rt_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx), it, dev), 2.0 * Bc * Tx * Ty * Ca),
         "alignment search + dense path (maxpath_pipelined_kernel)": (event_time_us(lambda: aligner_amd.align(logp, tx, ty), it, dev), 0.0),
     }
     # beside the step: what an OTA training step adds on the same log-probs -- the forward-sum objective with its gradient
@@ -900,7 +901,7 @@ def main():
         t_scat = event_time_us(step.scatter_path, it, dev) if side_on else float("nan")
         cells = B * TX * TY
         kernels = {
-            "softattn_kernel": {"us": t_sim, "bytes": 4 * B * C_ATT * (TX + TY) + 4 * cells},
+            SIM_KERNEL: {"us": t_sim, "bytes": 4 * B * C_ATT * (TX + TY) + 4 * cells},
             "maxpath_pipelined_kernel": {"us": t_fwd, "bytes": 4 * cells + 4 * B * (TX + TY)},
             "expand_kernel": {"us": t_exp, "bytes": 4 * cells + 4 * B * TY},
         }
@@ -911,14 +912,14 @@ def main():
         # the HBM-bound one).  The kernel with the longest duration is the alignment search, which SURVEY 8d prices as bound
         # by neither HBM nor MFMA (a dependent chain of T_mel steps on B of the 256 CUs): it is reported beside it as
         # `dominant_by_time` with "bound": "latency", its bytes-per-second for information only.
-        dom = "softattn_kernel"
+        dom = SIM_KERNEL
         longest = max(kernels, key=lambda k: kernels[k]["us"])
         ach = kernels[dom]["bytes"] / (kernels[dom]["us"] * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters: collected in separate rocprofv3 --pmc passes of this same
         # command (tools/pmc_traffic.py; gfx950 FETCH_SIZE correction applied) and committed under profiles/ --
         # not measured by this run, so the line names the file (and with it the build) the figure comes from
         traffic, traffic_src, traffic_all = None, None, {}
-        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02h_pmc_hbm_traffic.json"):
+        for name in ("r05_pmc_hbm_traffic.json",):     # (of THIS build's kernels: older files describe other kernels)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     traffic_all = json.load(f)["kernels"]
@@ -928,13 +929,13 @@ def main():
             except (OSError, ValueError, KeyError):
                 continue
         # wave occupancy of the search kernel from the SQ counters (rocprofv3 --pmc pass of this command,
-        # tools/pmc_issue.py -> profiles/r04_pmc_issue_counters.json): resident waves over the chip's wave slots while
+        # tools/pmc_issue.py -> profiles/r05_pmc_issue_counters.json): resident waves over the chip's wave slots while
         # the kernel runs; falls back to the launch geometry (B workgroups x 8 waves / 8192 slots) when the file is absent
         occ, occ_src = round(B * 8 / (256 * 32), 4), "launch geometry (B workgroups x 8 waves / 8192 wave slots)"
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_pmc_issue_counters.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r05_pmc_issue_counters.json")) as f:
                 pmc = json.load(f)["kernels"]["maxpath_pipelined_kernel"]
-            occ, occ_src = pmc["wave_occupancy"], "profiles/r04_pmc_issue_counters.json (4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8) / 8192 wave slots)"
+            occ, occ_src = pmc["wave_occupancy"], "profiles/r05_pmc_issue_counters.json (4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8) / 8192 wave slots)"
         except (OSError, ValueError, KeyError):
             pass
         dp_bytes, dp_us = kernels[longest]["bytes"], kernels[longest]["us"]

@@ -10,7 +10,7 @@ stream as 64 B, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as is."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-KERNELS = {"softattn_kernel": "softattn_kernel", "maxpath_pipelined_kernel": "maxpath_pipelined_kernel",
+KERNELS = {"softattn_rt_kernel": "softattn_rt_kernel", "softattn_kernel": "softattn_kernel", "maxpath_pipelined_kernel": "maxpath_pipelined_kernel",
            "expand_kernel": "expand_kernel",
            "mobo_forward_kernel": "mobo_forward_kernel"}
 

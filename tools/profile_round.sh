@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/profile_round.sh TAG -- the round's measurement set into gpurun_out/TAG/round
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-T=${1:-r04}; O=gpurun_out/$T/round; mkdir -p $O
+T=${1:-r05}; O=gpurun_out/$T/round; mkdir -p $O
 stats() { f=$(find $O/$1 -name "*kernel_stats.csv" | head -1); cp $f $O/$2; rm -rf $O/$1; head -7 $O/$2 | cut -c1-170; }
 # ---- headline (configs[1]) ----
 python3 bench.py > $O/bench.json 2> $O/bench.err
@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 benc
 stats stats bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > /dev/null 2> $O/pmc_write.err
-python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json "round 4 ($T)" > $O/pmc.txt 2>&1; rm -rf $O/pmc_fetch $O/pmc_write
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic.json "($T)" > $O/pmc.txt 2>&1; rm -rf $O/pmc_fetch $O/pmc_write
 # ---- configs[2]: the full pipeline ----
 python3 bench.py --config c3 > $O/bench_c3.json 2> $O/bench_c3.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c3 -- python3 bench.py --config c3 --no-cpu-baseline > /dev/null 2> $O/stats_c3.err
