@@ -24,6 +24,7 @@ unsigned long long *g_debug_stamps = nullptr;
 static int env_flag(const char *name) { const char *e = getenv(name); return e && e[0] && e[0] != '0'; }
 int g_opt_fwdsum_one_wave = env_flag("ALIGNER_FWDSUM_ONE_WAVE");
 int g_opt_fwdsum_serial = env_flag("ALIGNER_FWDSUM_SERIAL");
+int g_opt_fwdsum_no_grad_stager = 0;
 int g_opt_softattn_exact = env_flag("ALIGNER_SOFTATTN_EXACT");
 int g_opt_mobo_drop_segment = -1;
 int g_opt_mobo_start_lag = 0;
@@ -114,6 +115,7 @@ void aligner_debug_set_stamps(void *stamps_dev) {
 int aligner_debug_set_option(const char *name, int value) {
     if (!name) return aligner::fail(ALIGNER_EINVAL, "null option name");
     if (std::strcmp(name, "fwdsum_one_wave") == 0) { aligner::g_opt_fwdsum_one_wave = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "fwdsum_no_grad_stager") == 0) { aligner::g_opt_fwdsum_no_grad_stager = value; return ALIGNER_OK; }
     if (std::strcmp(name, "fwdsum_serial") == 0) { aligner::g_opt_fwdsum_serial = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_exact") == 0) { aligner::g_opt_softattn_exact = value; return ALIGNER_OK; }
     if (std::strcmp(name, "mobo_start_lag") == 0) { aligner::g_opt_mobo_start_lag = value; return ALIGNER_OK; }

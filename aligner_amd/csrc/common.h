@@ -60,6 +60,7 @@ extern int g_opt_softattn_no_pair;     // "softattn_no_pair": testing, the simil
 extern int g_opt_mobo_bwd_general;     // "mobo_bwd_general": testing, the gradient's chain in its general (one exp2 per term) form
 extern int g_opt_mobo_lanes;           // "mobo_lanes": development, lanes per position in the split form (0: the plan's choice)
 extern int g_opt_mobo_drop_segment;    // "mobo_drop_segment": testing, that position segment never publishes (-1: off)
+extern int g_opt_fwdsum_no_grad_stager; // "fwdsum_no_grad_stager": A-B / testing, the gradient-making backward kernel with its compiler-scheduled stager
 extern int g_opt_fwdsum_serial;        // "fwdsum_serial": forward then backward sweep, never side by side (A/B, tests)
 extern int g_opt_fwdsum_one_wave;      // aligner_debug_set_option("fwdsum_one_wave", ...); default: env, read once
 

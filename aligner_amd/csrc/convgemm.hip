@@ -1023,7 +1023,6 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
         }
         rc = conv_launch(P, p, L[i].K, split, s);
         if (rc != ALIGNER_OK) return rc;
-        if (getenv("ALIGNER_CONV_SYNC")) (void)hipStreamSynchronize(s);
         if (split) cur ^= 1;
         else if (!last) f32 = tmp;
     }

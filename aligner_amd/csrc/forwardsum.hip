@@ -60,6 +60,7 @@ struct FwdSumParams {
     int B, Tx, Ty, NT;
     double *doffs;          // workspace [B,SY_NW_MAX,NT]: D_w per (wave, frame) -- the sweeps-side-by-side form only
     unsigned long long *stamps;   // development (aligner_debug_set_stamps): per (workgroup, wave) 8 words of phase cycle totals
+    int no_grad_stager;     // A-B / testing ("fwdsum_no_grad_stager"): the gradient-making backward kernel keeps its compiler-scheduled stager
 };
 
 // log2(2^a + 2^b).  The log term is in (0, 1]: its absolute error (~1 ulp of the hardware log2/exp2)
@@ -254,8 +255,131 @@ __device__ __forceinline__ void fs_stager_by_hand(const float *in_g, float *out_
         for (int d = 0; d < D; ++d)
             if (ph + d < nph) phase(ph + d, q[d]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // the loads nobody consumed
+#pragma unroll
+    for (int d = 0; d < D; ++d) FsWait<NJ, 0>::on(q[d]);                       // the loads nobody consumed: every set named
     if (st && lane == 0) { st[0] = sa[0]; st[1] = sa[1]; st[2] = sa[2]; st[3] = sa[3]; st[4] = (unsigned long long)(nph - lag); }
+}
+
+// ---- the gradient-making backward kernel's stager (batches past half the CU count: forward, then backward) ----
+// A tile here is three things: the log-probs, ALPHA (same rows and frames: same per-lane offsets, another base) and the
+// wave's forward offsets C_w of the tile's frames (SY_TW doubles: one 8-byte load, lanes < SY_TW).  2 NJ + 1 loads a tile,
+// all hand-issued, FS_GDEPTH tiles in flight in FS_GDEPTH register sets; the order inside a phase is again wait - LDS
+// writes - stores - loads, so behind a tile's loads there are at least (2 NJ + 1)(D - 1) newer operations and
+// vmcnt((2 NJ + 1)(D - 1)) is always enough.  EVERY register of a set is named by the wait that retires it ("+v"): a
+// destination the compiler believes dead gets reassigned or spilled while the load is still landing (DESIGN.md rule 1;
+// round 4's first version of this stager faulted on its first run -- it carried four sets beside a kernel that already
+// spilled).  Three sets: the kernel stays inside its 256 registers without a spill
+// (tests/test_abi.py checks the compiler's resource report).
+constexpr int FS_GDEPTH = 3;
+__device__ __forceinline__ void fs_aload2(unsigned long long &dst, unsigned voff, const void *sbase) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int NJ, int CNT> struct FsWaitG;
+template <int CNT> struct FsWaitG<4, CNT> {
+    static __device__ __forceinline__ void on(fs_u32x4 (&a)[4], fs_u32x4 (&b)[4], unsigned long long &o) {
+        asm volatile("s_waitcnt vmcnt(%9)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]),
+                     "+v"(b[3]), "+v"(o) : "n"(CNT) : "memory");
+    }
+};
+template <int CNT> struct FsWaitG<2, CNT> {
+    static __device__ __forceinline__ void on(fs_u32x4 (&a)[2], fs_u32x4 (&b)[2], unsigned long long &o) {
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(o) : "n"(CNT) : "memory");
+    }
+};
+
+// lp_g / al_g / gr_g: the utterance's [Tx,Ty] blocks (log-probs and alpha in, gradient out); offs_g: this wave's forward
+// offsets per frame; tlp_w / tal_w / tgr_w: this wave's two LDS tiles each; toff_w: its two rows of offsets in LDS.
+// Slot r of a tile is text row 63 w + r (slot 63 is the ghost of the wave below); tiles run from the last to the first.
+template <int SY_TW>
+__device__ __forceinline__ void fs_grad_stager_by_hand(const float *lp_g, const float *al_g, float *gr_g, const double *offs_g,
+                                                       float *tlp_w, float *tal_w, const float *tgr_w, double *toff_w, int lag,
+                                                       int w, int lane, int tx, int ty, int Tx, int Ty, int ntl, int nph) {
+    constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, QR = SY_TW / 4, NJ = SY_TW / 4, D = FS_GDEPTH, OPS = 2 * NJ + 1;
+    static_assert(OPS * (D - 1) <= 63, "the counted wait's field");
+    fs_u32x4 ql[D][NJ], qa[D][NJ];
+    unsigned long long qo[D];
+    unsigned vo[NJ], vt[NJ], so[NJ];
+    unsigned long long mfull[NJ], mtail[NJ];
+    int rr[NJ], qd[NJ];
+    bool rowok[NJ];
+    const int tailq = (Ty - (ntl - 1) * SY_TW) / 4;          // quads of the last tile that lie inside the tensor (>= QR: all)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e4 = lane + 64 * j;
+        rr[j] = e4 / QR;
+        qd[j] = e4 - rr[j] * QR;
+        const int rs = 63 * w + rr[j];
+        const int rg = rs < tx ? rs : tx - 1;
+        const int qc = qd[j] < tailq ? qd[j] : tailq - 1;    // the last tile: quads past the tensor re-read the last one inside
+        vo[j] = (unsigned)(((size_t)rg * Ty + 4 * qd[j]) * sizeof(float));
+        vt[j] = (unsigned)(((size_t)rg * Ty + 4 * qc) * sizeof(float));
+        const bool sv = rr[j] < 63 && rs < Tx;
+        so[j] = (unsigned)(((size_t)(rs < Tx ? rs : 0) * Ty + 4 * qd[j]) * sizeof(float));
+        mfull[j] = __builtin_amdgcn_ballot_w64(sv);
+        mtail[j] = __builtin_amdgcn_ballot_w64(sv && qd[j] < tailq);
+        rowok[j] = rs < tx;                                   // rows past the text are staged as log 0
+    }
+    const bool allok = 63 * w + 63 < tx;                      // (uniform: most waves select nothing)
+    const int fl = lane & (SY_TW - 1);                        // this lane's frame of a tile's offsets
+    auto issue = [&](int k, fs_u32x4 (&sl)[NJ], fs_u32x4 (&sa)[NJ], unsigned long long &o) {
+        const int t = ntl - 1 - (k < ntl ? k : ntl - 1);      // k-th tile from the end, clamped
+        const char *bl = reinterpret_cast<const char *>(lp_g) + (size_t)t * SY_TW * sizeof(float);
+        const char *ba = reinterpret_cast<const char *>(al_g) + (size_t)t * SY_TW * sizeof(float);
+        const bool last = t == ntl - 1;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fs_aload4(sl[j], last ? vt[j] : vo[j], bl);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fs_aload4(sa[j], last ? vt[j] : vo[j], ba);
+        const int yo = t * SY_TW + fl;
+        fs_aload2(o, (unsigned)((yo < ty ? yo : ty - 1) * sizeof(double)), offs_g);
+    };
+    auto phase = [&](int ph, fs_u32x4 (&sl)[NJ], fs_u32x4 (&sa)[NJ], unsigned long long &o) {
+        const int k = ph - lag, ks = ph - 2 - lag;
+        FsWaitG<NJ, OPS * (D - 1)>::on(sl, sa, o);            // tile k has landed (see above)
+        if (k < ntl) {
+            float *dl = tlp_w + (k & 1) * SY_TILE, *da = tal_w + (k & 1) * SY_TILE;
+            const int y0 = (ntl - 1 - k) * SY_TW;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float f[4], a[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const unsigned rl = sl[j][jj], ra = sa[j][jj];        // (bit_cast straight from the vector element reads element 0)
+                    f[jj] = (allok || rowok[j]) ? fs_nat(__builtin_bit_cast(float, rl)) : FS_NEG_NAT;
+                    a[jj] = __builtin_bit_cast(float, ra);
+                }
+                *reinterpret_cast<float4 *>(dl + rr[j] * PITCH + 4 * qd[j]) = make_float4(f[0], f[1], f[2], f[3]);   // one ds_write_b128
+                *reinterpret_cast<float4 *>(da + rr[j] * PITCH + 4 * qd[j]) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            if (lane < SY_TW) toff_w[(k & 1) * SY_TW + lane] = (y0 + lane < ty) ? __builtin_bit_cast(double, o) : 0.0;
+        }
+        if (ks >= 0 && ks < ntl) {
+            const float *src = tgr_w + (ks & 1) * SY_TILE;
+            const int t = ntl - 1 - ks, y0 = t * SY_TW;
+            char *base = reinterpret_cast<char *>(gr_g) + (size_t)y0 * sizeof(float);
+            const bool last = t == ntl - 1;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 f = *reinterpret_cast<const float4 *>(src + rr[j] * PITCH + 4 * qd[j]);       // one ds_read_b128
+                fs_u32x4 d;
+                d[0] = __builtin_bit_cast(unsigned, f.x); d[1] = __builtin_bit_cast(unsigned, f.y);
+                d[2] = __builtin_bit_cast(unsigned, f.z); d[3] = __builtin_bit_cast(unsigned, f.w);
+                fs_astore4(so[j], d, base, last ? mtail[j] : mfull[j]);
+            }
+        }
+        issue(k + D, sl, sa, o);                              // (behind the stores: the wait's count)
+        fs_lds_barrier();
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(d, ql[d], qa[d], qo[d]);
+    for (int ph = 0; ph < lag; ++ph) fs_lds_barrier();        // (this stager's first tile is due in phase `lag`)
+    for (int ph = lag; ph < nph; ph += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (ph + d < nph) phase(ph + d, ql[d], qa[d], qo[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) FsWaitG<NJ, 0>::on(ql[d], qa[d], qo[d]);     // the loads nobody consumed: every set named
 }
 
 // ---- forward: alpha (frame y relative to C_y), the offsets, log Z, loss ----
@@ -740,7 +864,7 @@ __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_forward_sys_kernel(FwdS
 // beta do not depend on each other, only the posterior needs both): no alpha, no offsets, no log Z come in; what goes out
 // through the gradient tile is beta itself, relative to the wave's offset of that frame (D_w[y], to p.doffs), into
 // p.grad -- which fwdsum_combine_kernel then turns into the gradient in place.
-template <int SY_NW, int SY_TW, bool BETA_ONLY>
+template <int SY_NW, int SY_TW, bool BETA_ONLY, bool GRADHAND = false>
 __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, const int b) {
     constexpr int PITCH = SY_TW + 4, SY_TILE = 64 * PITCH, SY_THREADS = 2 * SY_NW * 64;   // slot-major tiles (see the forward kernel)
     extern __shared__ __attribute__((aligned(16))) float fs_smem[];
@@ -783,7 +907,15 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
     const bool by_hand = BETA_ONLY && p.Ty % 4 == 0 &&
                          ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.grad)) & 15) == 0 &&
                          (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
-    if (!sweeper && by_hand) {
+    // GRADHAND (the host checked: T_mel % 4 == 0, 16-byte aligned tensors, 32-bit offsets): the gradient-making kernel
+    // with the hand-issued stager and NOTHING of the compiler-scheduled one in it -- that one spills (9 registers), and
+    // a kernel that spills must not have hand-issued loads in flight
+    if (GRADHAND) {
+        if (!sweeper)
+            fs_grad_stager_by_hand<SY_TW>(p.logp + ubase, p.alpha + ubase, p.grad + ubase, offs, tlp + w * 2 * SY_TILE,
+                                          tal + w * 2 * SY_TILE, tgr + w * 2 * SY_TILE, toff + w * 2 * SY_TW, wr, w, lane, tx, ty,
+                                          p.Tx, p.Ty, ntl, ntl + SY_NW + 1);
+    } else if (!sweeper && by_hand) {
         fs_stager_by_hand<SY_TW, true>(p.logp + ubase, p.grad + ubase, doffs, tlp + w * 2 * SY_TILE, tgr + w * 2 * SY_TILE,
                                        tdof + w * 2 * SY_TW, wr, w, lane, tx, ty, p.Tx, p.Ty, ntl, ntl + SY_NW + 1);
     } else if (!sweeper) {
@@ -871,7 +1003,8 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
             phase(ph, sA);
             if (ph + 1 < nph) phase(ph + 1, sB);
         }
-    } else {
+    }
+    if (sweeper) {
         // (the frame's work is arranged as in fwdsum_forward_sys_body: no per-row select, offsets linear inside a group)
         double Dg = 0.0;                                      // this wave's offset at the start of the current group
         for (int ph = 0; ph < ntl + SY_NW + 1; ++ph) {
@@ -980,9 +1113,9 @@ __device__ __forceinline__ void fwdsum_backward_sys_body(const FwdSumParams &p, 
     }
 }
 
-template <int SY_NW, int SY_TW>
+template <int SY_NW, int SY_TW, bool GRADHAND>
 __global__ __launch_bounds__(2 * SY_NW * 64) void fwdsum_backward_sys_kernel(FwdSumParams p) {
-    fwdsum_backward_sys_body<SY_NW, SY_TW, false>(p, blockIdx.x);
+    fwdsum_backward_sys_body<SY_NW, SY_TW, false, GRADHAND>(p, blockIdx.x);
 }
 
 // The two sweeps side by side (2B workgroups <= the CUs): alpha runs forward and beta backward through the same log-probs
@@ -1863,7 +1996,11 @@ static int fs_launch_sys(const FwdSumParams &p, bool backward, hipStream_t s) {
     const size_t lds_b = 3 * SY_NW * 2 * tile + (size_t)SY_NW * (2 * SY_TW + 64 * 4) * sizeof(float) +
                          (size_t)2 * SY_NW * 2 * SY_TW * sizeof(double) + grp;
     auto kf = fwdsum_forward_sys_kernel<SY_NW, SY_TW>;
-    auto kb = fwdsum_backward_sys_kernel<SY_NW, SY_TW>;
+    const bool gradhand = backward && p.Ty % 4 == 0 && !p.no_grad_stager &&
+                          ((reinterpret_cast<uintptr_t>(p.logp) | reinterpret_cast<uintptr_t>(p.grad) |
+                            reinterpret_cast<uintptr_t>(p.alpha)) & 15) == 0 &&
+                          (size_t)p.Tx * p.Ty * sizeof(float) < (1ull << 32);
+    auto kb = gradhand ? fwdsum_backward_sys_kernel<SY_NW, SY_TW, true> : fwdsum_backward_sys_kernel<SY_NW, SY_TW, false>;
     // with the gradient, on a batch that leaves half the CUs idle: both sweeps in one launch, then the combining pass
     if (backward && g_opt_fwdsum_serial <= 0 && fs_side_by_side(p.B) && p.doffs) {
         auto k2 = fwdsum_both_sys_kernel<SY_NW, SY_TW>;
@@ -1978,7 +2115,7 @@ int aligner_forward_sum_f32(const float *logp, const int32_t *t_xs, const int32_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     FwdSumParams p{logp, t_xs, t_ys, reinterpret_cast<float *>(ws + L.alpha_off),
                    reinterpret_cast<double *>(ws + L.offs_off), reinterpret_cast<double *>(ws + L.logz_off),
-                   loss_out, grad_out, B, Tx, Ty, L.NT, reinterpret_cast<double *>(ws + L.doffs_off), g_debug_stamps};
+                   loss_out, grad_out, B, Tx, Ty, L.NT, reinterpret_cast<double *>(ws + L.doffs_off), g_debug_stamps, g_opt_fwdsum_no_grad_stager};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bwd = grad_out != nullptr;
     if (!g_opt_fwdsum_one_wave) {

@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define ALIGNER_ABI_VERSION 3
+/* 4: aligner_maxpath_workspace_bytes grew (per-utterance mask verdicts), aligner_fused_align_f32 left the library,
+ *    the prepared-weights image of round 4 (old image + the GEMM form's) and the forward-sum / search workspaces of round 4
+ *    are what the *_bytes functions of THIS version return: size every buffer with them, never with constants. */
+#define ALIGNER_ABI_VERSION 4
 
 /* error codes */
 #define ALIGNER_OK       0

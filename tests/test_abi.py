@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(built_lib):
 
 
 def test_abi_version_and_errors(built_lib):
-    assert built_lib.aligner_abi_version() == 3
+    assert built_lib.aligner_abi_version() == 4
     assert built_lib.aligner_maxpath_workspace_bytes(64, 200, 1000) > 64 * 32 * 256 * 4
     assert built_lib.aligner_maxpath_workspace_bytes(1, 0, 5) == 0
     # argument validation happens before any HIP call
@@ -129,3 +129,29 @@ def test_generated_asm_is_in_sync(tmp_path, name):
     gen.OUT = str(tmp_path / "generated.inc")
     gen.main()
     assert open(gen.OUT).read() == committed
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    """The compiler's resource report of every kernel in the library (kept beside the objects by the build:
+    aligner_amd/lib/obj/*.resources.txt, `-Rpass-analysis=kernel-resource-usage`): no spilled VGPR, no scratch.
+    Besides the speed: the kernels that issue their loads by hand (inline-asm global_load / LDS-DMA with counted
+    s_waitcnt) are only correct while the compiler never moves, spills or reuses a destination register behind an
+    in-flight load -- a kernel that spills gives no such guarantee (rules 1 and 11).  The two exceptions are
+    named: neither issues a load by hand."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    files = glob.glob(os.path.join(kr.OBJ, "*.hip.resources.txt"))
+    assert len(files) >= 6, "no resource reports: build the library first (python -c 'import __graft_entry__ as g; g.build()')"
+    rows = [(os.path.basename(f), name, v) for f in sorted(files) for name, v in kr.parse(f)]      # (mangled names)
+    assert len(rows) > 300
+    allowed = ("fwdsum_backward_sys_kernelILi4ELi16ELb0E", "fwdsum_backward_sys_kernelILi8ELi8ELb0E",   # compiler-scheduled stager
+               "mobo_norm_kernel")                                                                       # (tensors not 16-byte aligned)
+    bad = [(src, name, v.get("VGPRs Spill", 0), v.get("ScratchSize [bytes/lane]", 0)) for src, name, v in rows
+           if (v.get("VGPRs Spill", 0) or v.get("ScratchSize [bytes/lane]", 0)) and not any(a in name for a in allowed)]
+    assert not bad, bad
+    for key in ("softattn_rt_kernel", "maxpath_pipelined_kernel", "expand_kernel", "conv_gemm_kernel", "fwdsum_both_sys_kernel",
+                "fwdsum_backward_sys_kernelILi4ELi16ELb1E"):
+        assert any(key in name for _, name, _ in rows), key

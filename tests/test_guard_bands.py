@@ -263,6 +263,28 @@ def test_boundary_search_gradient_writes_stay_inside_their_buffers(dev, B, Tx, T
     assert too_small == -28                                         # ALIGNER_ENOSPC
 
 
+@pytest.mark.parametrize("B,Tx,Ty", [(2, 200, 1000), (3, 63, 200), (2, 300, 504), (129, 30, 64)])
+def test_forward_sum_serial_form_writes_stay_inside_their_buffers(dev, request, B, Tx, Ty):
+    """forward, then the gradient-making backward kernel with its hand-issued stager (fs_grad_stager_by_hand): the form
+    batches past half the CU count take; forced on the small ones."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Tx * 3 + Ty)
+    logp = torch.log_softmax(torch.randn(B, Tx, Ty, generator=g), dim=1).to(dev)
+    t_x = torch.tensor([Tx] + [max(1, Tx - 5 * (i % 7)) for i in range(1, B)], dtype=torch.int32, device=dev)
+    t_y = torch.tensor([Ty] + [max(Tx, Ty - 3 * (i % 11)) for i in range(1, B)], dtype=torch.int32, device=dev)
+    wsb = lib.aligner_forward_sum_workspace_bytes(B, Tx, Ty)
+    ws, loss, grad = Fenced(wsb, dev), Fenced(B * 4, dev), Fenced(B * Tx * Ty * 4, dev)
+    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"fwdsum_serial", 0))
+    _lib.check(lib.aligner_debug_set_option(b"fwdsum_serial", 1))
+    _lib.check(lib.aligner_forward_sum_f32(logp.data_ptr(), t_x.data_ptr(), t_y.data_ptr(), loss.ptr, grad.ptr, ws.ptr, wsb,
+                                           B, Tx, Ty, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for name, f in (("forward-sum workspace", ws), ("loss", loss), ("grad", grad)):
+        assert f.intact(), f"{name}: a kernel wrote outside its buffer"
+    post = -grad.view(torch.float32, (B, Tx, Ty))[0, :, :int(t_y[0])].sum(0)       # a frame's posterior sums to 1
+    assert float((post - 1).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("B,Tx,Ty", [(2, 9, 40), (2, 200, 1000), (2, 255, 400), (1, 300, 500), (1, 600, 900)])
 def test_forward_sum_ctc_form_writes_stay_inside_their_buffers(dev, B, Tx, Ty):
     lib = _lib.load()

@@ -338,6 +338,45 @@ def test_forward_sum_side_by_side_sweeps_equal_the_serial_form(dev, request, B, 
         assert not grad_p[1].any() and torch.isinf(loss_p[1])
 
 
+# Batches past half the CU count (and `fwdsum_serial`) run forward, then the gradient-making backward kernel, whose stager
+# (log-probs + alpha + the forward offsets per tile) issues its loads by hand too (fs_grad_stager_by_hand): the same tiles
+# reach LDS as with the compiler-scheduled stager (`fwdsum_no_grad_stager`), so the two must agree BIT FOR BIT; and against
+# the oracle.  Shapes: a partial last tile (T_mel % 16 != 0), ragged lengths, text ending inside a wave, both widths of
+# the systolic kernels (T_text <= 252: four waves, 16-frame tiles; <= 504: eight waves, 8-frame tiles), [160,200,1000].
+@gpu
+@pytest.mark.parametrize("B,Tx,Ty", [(3, 200, 1000), (5, 40, 132), (2, 251, 520), (2, 300, 704), (4, 504, 808), (130, 20, 64),
+                                     (160, 200, 1000)])
+def test_gradient_stager_by_hand(dev, request, B, Tx, Ty):
+    import aligner_amd
+    from aligner_amd import _lib
+    rng = np.random.default_rng(7 * B + Tx)
+    lp_h = _rand_logp(rng, B, Tx, Ty)
+    lp = torch.from_numpy(lp_h).to(dev)
+    ty = rng.integers(max(Tx // 2, 2), Ty + 1, size=B)
+    tx = np.minimum(rng.integers(1, Tx + 1, size=B), ty)
+    tx[0], ty[0] = Tx, Ty
+    if B > 2:
+        tx[1], ty[1] = min(Tx, 9), 5                              # fewer frames than tokens: loss +inf, gradient 0
+    lib = _lib.load()
+    request.addfinalizer(lambda: (lib.aligner_debug_set_option(b"fwdsum_serial", 0),
+                                  lib.aligner_debug_set_option(b"fwdsum_no_grad_stager", 0)))
+    _lib.check(lib.aligner_debug_set_option(b"fwdsum_serial", 1))
+    loss_h, grad_h = aligner_amd.forward_sum(lp, torch.from_numpy(tx), torch.from_numpy(ty))
+    grad_h = grad_h.clone()
+    _lib.check(lib.aligner_debug_set_option(b"fwdsum_no_grad_stager", 1))
+    loss_c, grad_c = aligner_amd.forward_sum(lp, torch.from_numpy(tx), torch.from_numpy(ty))
+    torch.cuda.synchronize()
+    assert torch.equal(loss_h, loss_c) and torch.equal(grad_h.view(torch.int32), grad_c.view(torch.int32))
+    nb = min(B, 4)                                                # the float64 oracle on the first utterances
+    want_loss, want_grad = FS.forward_sum(lp_h[:nb], tx[:nb], ty[:nb])
+    g = grad_h[:nb].cpu().numpy().astype(np.float64)
+    fin = np.isfinite(want_loss)
+    assert np.abs(loss_h[:nb].cpu().numpy().astype(np.float64)[fin] - want_loss[fin]).max() <= 5e-4 + 2e-7 * np.abs(want_loss[fin]).max()
+    assert (np.abs(g - want_grad) <= 1e-3 * np.abs(want_grad) + 2e-5).all()
+    for b in range(B):
+        assert not grad_h[b, int(tx[b]):].any() and not grad_h[b, :, int(ty[b]):].any()
+
+
 # The systolic kernels' stagers issue 16-byte global accesses by hand when T_mel % 4 == 0 and the tensors are 16-byte
 # aligned; anything else takes the compiler-scheduled stager.  A log-prob tensor that starts 4 bytes into its buffer must
 # give the same numbers (and no misaligned access).

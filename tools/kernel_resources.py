@@ -14,7 +14,7 @@ FIELDS = ["VGPRs", "AGPRs", "TotalSGPRs", "VGPRs Spill", "SGPRs Spill", "Scratch
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
         return out.split("\n")[:len(names)]
     except OSError:
         return names
@@ -41,8 +41,11 @@ def table():
         ks = parse(f)
         names = demangle([k for k, _ in ks])
         for (mangled, v), name in zip(ks, names):
-            name = re.sub(r"^void ", "", name)
-            name = re.sub(r"\(aligner::\w+Params\)$|\(.*\)$", "", name).replace("aligner::", "")
+            if name and name != mangled:
+                name = re.sub(r"^void ", "", name)
+                name = re.sub(r"\(aligner::\w+Params\)$|\(.*\)$", "", name).replace("aligner::", "")
+            else:
+                name = mangled
             rows.append((os.path.basename(f).replace(".resources.txt", ""), name, v))
     return rows
 
