@@ -64,3 +64,40 @@ def test_self_launched_two_ranks_on_one_gpu_print_one_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
     assert d["guards"] and all(v is not False for v in d["guards"].values()) and d["guards"]["durations_match_gathered"] is True
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_path_of_the_headline_bench():
+    """The multi-rank code path of `bench.py` with the REAL backend on one rank (ALIGNER_BENCH_FORCE_DIST=1: a 1-rank
+    RCCL process group, the durations gathered in buckets on the communication stream, captured graphs): the first
+    `--gpus 8` run is the driver's, this is what can be exercised on one GPU.  One JSON line, every guard true, and the
+    gather gave back what the kernels wrote."""
+    import json
+    r = _run(["--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-side-kernels"],
+             {"ALIGNER_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29561", "RANK": "0", "WORLD_SIZE": "1",
+              "LOCAL_RANK": "0"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
+    g = d["guards"]
+    assert g and all(v is not False for v in g.values())
+    assert g["durations_match_gathered"] is True and g["path_matches_reference_hash"] is True
+    assert d["roofline"]["kernel"] == "softattn_rt_kernel" and d.get("cpu_baseline") is None
+
+
+@pytest.mark.gpu
+def test_c4_as_a_two_rank_job_matches_the_reference_hashes():
+    """BASELINE configs[3] (512 ragged utterances, batch-sharded, durations gathered) self-launched with two ranks in the
+    rehearsal form (both on GPU 0, gloo): every shard's gathered durations hash to SURVEY Appendix A's values."""
+    import json
+    r = _run(["--config", "c4", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+             {"ALIGNER_BENCH_REHEARSE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["utterances"] == 512
+    assert d["durations_match_reference_hashes"] is True
+    assert len(d["load_balance"]["dp_kernel_us_per_rank"]) == 2
