@@ -40,6 +40,7 @@ int g_opt_conv_split_always = env_flag("ALIGNER_CONV_SPLIT_ALWAYS");
 int g_opt_maxpath_no_split_walk = 0;
 int g_opt_maxpath_zero_blocks = 0;
 int g_opt_maxpath_no_mask_verify = 0;
+int g_opt_maxpath_no_optimistic_mask = 0;
 int g_opt_mobo_full_chain = 0;
 int g_opt_mobo_stamp_wave = 0;
 
@@ -126,6 +127,7 @@ int aligner_debug_set_option(const char *name, int value) {
     if (std::strcmp(name, "conv_narrow_ft") == 0) { aligner::g_opt_conv_narrow_ft = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_no_fuse") == 0) { aligner::g_opt_conv_no_fuse = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_split_always") == 0) { aligner::g_opt_conv_split_always = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "maxpath_no_optimistic_mask") == 0) { aligner::g_opt_maxpath_no_optimistic_mask = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_mask_verify") == 0) { aligner::g_opt_maxpath_no_mask_verify = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_zero_blocks") == 0) { aligner::g_opt_maxpath_zero_blocks = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_split_walk") == 0) { aligner::g_opt_maxpath_no_split_walk = value; return ALIGNER_OK; }

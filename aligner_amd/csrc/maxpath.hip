@@ -75,7 +75,9 @@ struct MaxpathParams {
     int         *dur;       // [B,Tx] nullable
     unsigned    *bits;      // [B,NT,ROWS] decision words in global memory
     int         *status;
-    const int   *mflag;     // MASKMODE 2: [B][MV_CHUNKS] nonzero = that piece of the utterance's mask is not all ones inside [0,t_x) x [0,t_y)
+    int         *mflag;     // [B][MV_CHUNKS] nonzero = that piece of the utterance's mask is not all ones inside [0,t_x) x [0,t_y)
+    int          verify;    // the launch's zero workgroups also verify p.mask (strict mask, optimistic search: see the kernel)
+    int          redo;      // MASKMODE 1: only the utterances a verdict in mflag names, their earlier ones erased first
     int B, Tx, Ty, NT, ROWS;
     int WT;                 // tiles per backtrack window when the words live in global memory
     int bits_in_lds;        // pipelined kernel: decision words stay in LDS
@@ -1340,6 +1342,66 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
     ALIGNER_STAMP(7);
 }
 
+// One piece (a range of rows of one utterance) of the mask's rectangle [0,t_x) x [0,t_y): all ONES of the mask's
+// dtype?  (mask_verify_kernel's test with the lengths known; here run by the search launch's zero workgroups.)
+template <int VT, int NTHREADS>
+__device__ __forceinline__ void verify_mask_piece(const MaxpathParams &p, int q) {
+    constexpr int ES = VT == VT_F32 ? 4 : 2, EPV = 16 / ES, NWV = NTHREADS / 64;
+    typedef typename std::conditional<ES == 4, unsigned, unsigned short>::type U;
+    const unsigned one_bits = VT == VT_F32 ? 0x3F800000u : VT == VT_BF16 ? 0x3F80u : 0x3C00u;
+    const unsigned w1 = ES == 4 ? one_bits : (one_bits | (one_bits << 16));
+    const int b = q / MV_CHUNKS, c = q - b * MV_CHUNKS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = p.t_xs[b], ty = p.t_ys[b];
+    int bad = 0;
+    if (!(tx >= 1 && tx <= ty && tx <= p.Tx && ty <= p.Ty)) {
+        bad = 1;                                                     // not the normal mode: the multiply stays
+    } else {
+        const U *mu = static_cast<const U *>(p.mask) + (size_t)b * p.Tx * p.Ty;
+        const int per = (tx + MV_CHUNKS - 1) / MV_CHUNKS;
+        const int r0 = c * per, r1 = r0 + per < tx ? r0 + per : tx;
+        const bool vec = (p.Ty % EPV == 0) && ((reinterpret_cast<uintptr_t>(p.mask) & 15) == 0);
+        const int nq = vec ? ty / EPV : 0;
+        for (int x = r0 + wave; x < r1; x += NWV) {                  // a wave per row: coalesced 1 KB runs
+            const uint4 *row = reinterpret_cast<const uint4 *>(mu + (size_t)x * p.Ty);
+            int k = lane;
+            for (; k + 192 < nq; k += 256) {                         // four loads in flight per lane
+                const uint4 v0 = row[k], v1 = row[k + 64], v2 = row[k + 128], v3 = row[k + 192];
+                bad |= (v0.x != w1) | (v0.y != w1) | (v0.z != w1) | (v0.w != w1) | (v1.x != w1) | (v1.y != w1) |
+                       (v1.z != w1) | (v1.w != w1) | (v2.x != w1) | (v2.y != w1) | (v2.z != w1) | (v2.w != w1) |
+                       (v3.x != w1) | (v3.y != w1) | (v3.z != w1) | (v3.w != w1);
+            }
+            for (; k < nq; k += 64) {
+                const uint4 v = row[k];
+                bad |= (v.x != w1) | (v.y != w1) | (v.z != w1) | (v.w != w1);
+            }
+            for (int y = nq * EPV + lane; y < ty; y += 64) bad |= mu[(size_t)x * p.Ty + y] != (U)one_bits;
+        }
+    }
+    const int any = __syncthreads_or(bad);
+    if (tid == 0) p.mflag[q] = any;
+}
+
+// The redo of an utterance whose optimistic search ran on unmasked scores: the ones that search wrote into the dense path
+// (frames [starts[x], starts[x+1]) of row x, as store_outputs marked them) become zeros again before the strict search
+// writes its own.  The erasing stores are drained and the workgroup meets before anything else is stored.
+__device__ __forceinline__ void erase_path_ones(const MaxpathParams &p, int b) {
+    const int *st = p.starts + (size_t)b * (p.Tx + 1);
+    for (int x = threadIdx.x; x < p.Tx; x += blockDim.x) {
+        const int s0 = st[x], s1 = st[x + 1];
+        for (int y = s0; y < s1 && y < p.Ty; ++y) {
+            const size_t idx = ((size_t)b * p.Tx + x) * p.Ty + y;
+            switch (p.path1_es) {
+                case 1: static_cast<unsigned char *>(p.path1)[idx] = 0; break;
+                case 2: static_cast<unsigned short *>(p.path1)[idx] = 0; break;
+                case 4: static_cast<unsigned *>(p.path1)[idx] = 0u; break;
+                default: static_cast<unsigned long long *>(p.path1)[idx] = 0ull; break;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // The launch.  With p.zero_blocks the grid is zero_blocks + B workgroups: the first ones -- on the CUs a batch of B
 // utterances leaves idle -- write the zeros of the dense path (np.zeros, __init__.py:15) while the others search, and
 // an utterance's workgroup writes its ones (core.pyx:33) once the zero workgroups have reported (store_outputs):
@@ -1370,6 +1432,20 @@ __global__ __launch_bounds__(NW * 128, 1) void maxpath_pipelined_kernel(MaxpathP
         __syncthreads();
         if (threadIdx.x == 0 && !(p.flags & ALIGNER_F_TEST_DROP_ZERO_REPORTS))                  // (testing: the zeros are written, never reported)
             __hip_atomic_fetch_add(p.zsync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the workgroup says so
+        // Strict mask, optimistic form: the searching workgroups of this launch took the scores as they are (no mask
+        // stream through their loaders, which sit at the CU's fetch limit); the zero workgroups, done with the zeros long
+        // before the search ends, now check that the multiply would have been the identity (verify_mask_piece) and leave a
+        // verdict per piece.  A second launch redoes, with the multiply, exactly the utterances a verdict names.
+        if (MASKMODE == 0 && p.verify)
+            for (int q = blockIdx.x; q < p.B * MV_CHUNKS; q += Z) verify_mask_piece<VT, NW * 128>(p, q);
+    } else if (MASKMODE == 1 && p.redo) {
+        const int b = (int)blockIdx.x;
+        static_assert(MV_CHUNKS <= 64, "one flag word per lane");
+        const int mine = (threadIdx.x & 63) < MV_CHUNKS ? p.mflag[b * MV_CHUNKS + (threadIdx.x & 63)] : 0;
+        if (__builtin_amdgcn_ballot_w64(mine != 0) != 0) {           // (uniform: every wave reads the same words)
+            if (p.path1) erase_path_ones(p, b);
+            maxpath_pipelined_body<NW, DEPTH, VEC, 1, VT, PAIR>(p, b);
+        }
     } else if (MASKMODE == 2) {
         // strict mask, decided per utterance on the device: mask_verify_kernel found the mask all ones wherever the
         // search reads a score (a 0/1 prefix rectangle, the usual x_mask * y_mask) -> value * mask IS value there and
@@ -1740,8 +1816,17 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     // then skips the mask stream (MASKMODE 2)
     // (up to four waves of text rows: the eight-wave workgroup has 128 registers a lane and its strict form keeps one
     // tile in flight instead of two to stay inside them; the two-workgroup form keeps the plain multiply)
-    const bool dyn_mask = (flags & ALIGNER_F_STRICT_MASK) && !(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_WRITE_Q)) &&
-                          (Tx + RPW - 1) / RPW <= 4 && !g_opt_maxpath_no_mask_verify;
+    bool dyn_mask = (flags & ALIGNER_F_STRICT_MASK) && !(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_WRITE_Q)) &&
+                    (Tx + RPW - 1) / RPW <= 4 && !g_opt_maxpath_no_mask_verify;
+    // ... and where the search launch has zero workgroups (it writes the dense path on the CUs the batch leaves idle),
+    // THEY verify the mask, beside an optimistic search, and a second launch redoes the utterances they flag: no pass
+    // over the mask in front of the search at all
+    const bool opt_mask = dyn_mask && path_out && !path_is_zero && !(flags & ALIGNER_F_SEPARATE_EXPAND) &&
+                          device_cu_count() - B >= 32 && (reinterpret_cast<uintptr_t>(path_out) & 15) == 0 &&
+                          ((size_t)B * Tx * Ty * dtype_size(path_dtype)) % 16 == 0 && dtype_size(path_dtype) > 0 &&
+                          (vt == VT_F32 || (Ty % 8 == 0 && (reinterpret_cast<uintptr_t>(value) & 15) == 0)) &&
+                          !g_opt_maxpath_no_optimistic_mask;
+    if (opt_mask) dyn_mask = false;
     if (dyn_mask) {
         int *lx = reinterpret_cast<int *>(wsb + L.len_off), *ly = lx + B;
         int *mf = reinterpret_cast<int *>(wsb + L.mflag_off);
@@ -1774,7 +1859,8 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.dur = dur_out;
     p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
     p.status = reinterpret_cast<int *>(wsb + L.status_off);
-    p.mflag = reinterpret_cast<const int *>(wsb + L.mflag_off);
+    p.mflag = reinterpret_cast<int *>(wsb + L.mflag_off);
+    p.verify = 0; p.redo = 0;
     p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
     p.neg = neg; p.flags = flags;
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0;
@@ -1799,7 +1885,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
         p.flags = flags;
     }
     const int maskmode = (flags & ALIGNER_F_STRICT_MASK) ? 1 : 0;
-    const int pipemask = dyn_mask ? 2 : maskmode;                       // the pipelined launches: decided per utterance on the device
+    const int pipemask = dyn_mask ? 2 : opt_mask ? 0 : maskmode;        // the pipelined launches: decided per utterance on the device
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
     const int per16 = vt == VT_F32 ? 4 : 8;                      // scores per 16-byte load
@@ -1893,12 +1979,24 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                     set_path_ones(p, path_out, path_dtype);
                     if (path_done) *path_done = true;
                 }
-                switch (NW) {
-                    case 1: return launch_pipelined<1, 4>(p, vec, pipemask, vt, lds, s);
-                    case 2: return launch_pipelined<2, 4>(p, vec, pipemask, vt, lds, s);
-                    case 4: return launch_pipelined<4, 2>(p, vec, pipemask, vt, lds, s);
-                    default: return launch_pipelined<8, 2>(p, vec, pipemask, vt, lds, s);
+                auto launch = [&](const MaxpathParams &q, int mm) {
+                    switch (NW) {
+                        case 1: return launch_pipelined<1, 4>(q, vec, mm, vt, lds, s);
+                        case 2: return launch_pipelined<2, 4>(q, vec, mm, vt, lds, s);
+                        case 4: return launch_pipelined<4, 2>(q, vec, mm, vt, lds, s);
+                        default: return launch_pipelined<8, 2>(q, vec, mm, vt, lds, s);
+                    }
+                };
+                if (opt_mask && p.zero_blocks > 0) {
+                    p.mask = mask;
+                    p.verify = 1;
+                    int rc = launch(p, 0);                         // optimistic search + zeros + verification
+                    if (rc != ALIGNER_OK) return rc;
+                    MaxpathParams r = p;                           // the redo of the flagged utterances: ones only, no zero workgroups
+                    r.verify = 0; r.redo = 1; r.zero_blocks = 0; r.zero_n16 = 0;
+                    return launch(r, 1);
                 }
+                return launch(p, opt_mask ? maskmode : pipemask);   // (no zero workgroups after all: the plain multiply)
             }
         }
     }

@@ -304,14 +304,31 @@ def test_strict_mask_verified_on_the_device(dev, request, dt, B, Tx, Ty):
         degen[1] = 0
         degen[1, :4, :2] = 1                                     # t_x = 4 > t_y = 2: the reference's raw-score walk
         cases["t_x > t_y"] = degen
-    request.addfinalizer(lambda: lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 0))
+    request.addfinalizer(lambda: (lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 0),
+                                  lib.aligner_debug_set_option(b"maxpath_no_optimistic_mask", 0)))
     for name, mask in cases.items():
+        # the library's choice (an optimistic search beside the verification on the zero workgroups + a redo of the flagged
+        # utterances, where the launch has zero workgroups), the verification as a pass in front of the search, and the
+        # multiply always: one answer.  Twice in a row: the redo erases the optimistic search's ones from the dense path
         got = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        again = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        assert lib.aligner_debug_set_option(b"maxpath_no_optimistic_mask", 1) == 0
+        front = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
+        lib.aligner_debug_set_option(b"maxpath_no_optimistic_mask", 0)
         assert lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 1) == 0
         mul = aligner_amd.maximum_path(v.to(dev), mask.to(dev))
         lib.aligner_debug_set_option(b"maxpath_no_mask_verify", 0)
         torch.cuda.synchronize()
-        assert got.dtype == dt and torch.equal(got, mul), name
+        assert got.dtype == dt and torch.equal(got, mul) and torch.equal(again, mul) and torch.equal(front, mul), name
+        # durations and token indices of the redone utterances too (align() with the mask multiplied in)
+        ra = aligner_amd.align(v.to(dev), mask=mask.to(dev), strict_mask=True, want_tok=True, compat_tx_gt_ty=True)
+        torch.cuda.synchronize()
+        assert torch.equal(ra.path, mul), name
+        assert torch.equal(ra.durations, mul.float().sum(2).to(torch.int32)), name
+        if name != "t_x > t_y":
+            lyv = mask[:, 0, :].float().sum(1).int()
+            tokw = torch.where(torch.arange(Ty)[None, :] < lyv[:, None], mul.float().argmax(1).cpu().to(torch.int32), -1)
+            assert torch.equal(ra.tok.cpu(), tokw), name
         if name != "t_x > t_y":
             lx = mask[:, :, 0].float().sum(1).int().numpy()
             ly = mask[:, 0, :].float().sum(1).int().numpy()
