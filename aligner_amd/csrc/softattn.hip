@@ -832,11 +832,13 @@ __device__ __forceinline__ float rt_merge(const float2 (&st)[NT]) {
 // 4 / 7 drained / entry on the 100 MHz clock; 8 + 4j, 9 + 4j: arrival at / release from barrier j
 #define RT_STAMP(k)                                                                                           \
     do {                                                                                                      \
-        if (p.stamps && (threadIdx.x & 63) == 0)                                                              \
+        if (STAMPS && p.stamps && (threadIdx.x & 63) == 0)                                                    \
             p.stamps[((size_t)blockIdx.x * (NT + 1) + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
-template <int KS, int NT, bool OUT16>
+// STAMPS: the development build with the cycle stamps (aligner_debug_set_stamps); in the product's instantiation they are
+// compiled out -- four "is the stamp buffer set" branches a strip were ~130 cycles of every wave's 2 400
+template <int KS, int NT, bool OUT16, bool STAMPS = false>
 __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnParams p) {
     constexpr int SLOTB = KS * 2048;                  // one strip: raw [16 KS channels][32 frames] fp32 == split [KS][hi, lo][64] x 16 B
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -865,7 +867,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
     const int NS = left >= 32 * RT_STRIPS ? RT_STRIPS : (left + 31) / 32;          // strips of this workgroup (>= 1)
     const float *Qb = p.queries + (size_t)b * p.C * p.Ty;
     RT_STAMP(0);
-    if (p.stamps && lane == 0)
+    if (STAMPS && p.stamps && lane == 0)
         p.stamps[((size_t)blockIdx.x * (NT + 1) + wave) * 64 + 7] = __builtin_amdgcn_s_memrealtime();
 
     // wave 0 is the loader (the first wave's loads are the first the CU's load path serves: the first strip is out
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         tmax = fmaxf(tmax, lgC[15]);
         float t0, t1;
         rt_halves(tmax, t0, t1);
-        tmax = fmaxf(t0, t1);
+        asm("v_max_f32_e32 %0, %1, %2" : "=v"(tmax) : "v"(t0), "v"(t1));      // (fmaxf would first canonicalise both operands)
         const float ms = (tmax == NEG_INF_F) ? 0.f : tmax;
         RT_STAMP(10 + 4 * j);
         __builtin_amdgcn_sched_barrier(0);
@@ -1233,7 +1235,7 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         }
     }
     RT_STAMP(5);
-    if (p.stamps) {                       // debug only: when have this wave's stores left the CU?
+    if (STAMPS && p.stamps) {             // debug only: when have this wave's stores left the CU?
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         RT_STAMP(6);
         if (lane == 0) p.stamps[((size_t)blockIdx.x * (NT + 1) + wave) * 64 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -2012,6 +2014,7 @@ static int launch_softattn_rt(const SoftAttnParams &p, hipStream_t s) {
     const size_t lds = (size_t)(rt_raw_slots(KS) + RT_RING) * KS * 2048 + (size_t)2 * NT * 32 * sizeof(float2) + (size_t)(NT + 2) * 32 * sizeof(float);
     static_assert(((rt_raw_slots(KS) + RT_RING) * KS * 2048 + 2 * NT * 32 * 8 + (NT + 2) * 32 * 4) <= 160 * 1024, "LDS");
     auto kern = softattn_rt_kernel<KS, NT, OUT16>;
+    if (p.stamps && KS == 5 && !OUT16) kern = softattn_rt_kernel<(KS == 5 ? KS : 5), NT, false, true>;     // (development: tools/sa_rt_stamps.py)
     SoftAttnParams q = p;
     q.pair = g_opt_softattn_rt_drop_merge ? -1 : 0;
     ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
