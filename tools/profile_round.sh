@@ -25,6 +25,10 @@ python3 bench.py --config c5 > $O/bench_c5.json 2> $O/bench_c5.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c5 -- python3 bench.py --config c5 --no-cpu-baseline > /dev/null 2> $O/stats_c5.err
 stats stats_c5 bench_c5_kernel_stats.csv
 python3 tools/c5_stamps.py > $O/dp_stamps_c5.txt 2>&1 || true
+python3 tools/sa_rt_stamps.py > $O/softattn_stamps.txt 2>&1 || true
+python3 tools/dropin_time.py > $O/dropin_times.txt 2>&1 || true
+python3 tools/fwdsum_serial_time.py > $O/fwdsum_serial_times.txt 2>&1 || true
+python3 tools/c5_zero_blocks.py > $O/c5_zero_workgroups.txt 2>&1 || true
 python3 tools/conv_fused_stamps.py > $O/conv_fused_stamps.txt 2>&1 || true
 python3 tools/config_times.py > $O/config_times.txt 2>&1 || true
 cat $O/streams_sweep.txt; head -30 $O/pmc.txt; python3 -c "
