@@ -55,8 +55,16 @@ extern "C" {
 /* flags for aligner_maxpath_* */
 #define ALIGNER_F_STRICT_MASK   1  /* multiply value by mask element-wise first
                                       (__init__.py:11) instead of using the mask
-                                      for lengths only.  Needed only for masks
-                                      that are not 0/1 prefix rectangles.      */
+                                      for lengths only.  The result is that of
+                                      the multiply, bit for bit; the multiply
+                                      itself happens only for the utterances whose
+                                      mask is not ONE on every score the search
+                                      reads (the rectangle [0,t_x) x [0,t_y)):
+                                      that is checked on the device, per
+                                      utterance -- by the workgroups that write
+                                      the dense path beside an optimistic search
+                                      (a second launch redoes the others), or by
+                                      a pass over the mask in front of it.      */
 #define ALIGNER_F_COMPAT_TXGTTY 2  /* t_x > t_y: reproduce the reference's
                                       result -- its forward band is empty, so
                                       its backtrack (core.pyx:32-35) walks up
