@@ -119,6 +119,12 @@ def load() -> ctypes.CDLL:
             fn = getattr(lib, name)            # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        # development: ALIGNER_DEBUG_OPTIONS="name=value,..." sets the library's A-B / testing switches
+        # (aligner_debug_set_option) for a whole process, e.g. under rocprofv3
+        for item in filter(None, os.environ.get("ALIGNER_DEBUG_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if lib.aligner_debug_set_option(name.strip().encode(), int(value or "1")) != 0:
+                raise ValueError(f"ALIGNER_DEBUG_OPTIONS: unknown option {name!r}")
         _lib = lib
     return _lib
 

@@ -35,6 +35,7 @@ int g_opt_softattn_rt_drop_merge = 0;
 int g_opt_softattn_strips = env_flag("ALIGNER_SOFTATTN_STRIPS");
 int g_opt_softattn_split = 0;
 int g_opt_conv_narrow_ft = 0;
+int g_opt_conv_no_ring = 0;
 int g_opt_conv_no_fuse = 0;
 int g_opt_conv_split_always = env_flag("ALIGNER_CONV_SPLIT_ALWAYS");
 int g_opt_maxpath_no_split_walk = 0;
@@ -125,6 +126,7 @@ int aligner_debug_set_option(const char *name, int value) {
     if (std::strcmp(name, "mobo_full_chain") == 0) { aligner::g_opt_mobo_full_chain = value; return ALIGNER_OK; }
     if (std::strcmp(name, "softattn_split") == 0) { aligner::g_opt_softattn_split = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_narrow_ft") == 0) { aligner::g_opt_conv_narrow_ft = value; return ALIGNER_OK; }
+    if (std::strcmp(name, "conv_no_ring") == 0) { aligner::g_opt_conv_no_ring = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_no_fuse") == 0) { aligner::g_opt_conv_no_fuse = value; return ALIGNER_OK; }
     if (std::strcmp(name, "conv_split_always") == 0) { aligner::g_opt_conv_split_always = value; return ALIGNER_OK; }
     if (std::strcmp(name, "maxpath_no_optimistic_mask") == 0) { aligner::g_opt_maxpath_no_optimistic_mask = value; return ALIGNER_OK; }

@@ -48,6 +48,7 @@ extern int g_opt_mobo_start_lag;       // "mobo_start_lag": rows a position segm
 extern int g_opt_mobo_stamp_wave;      // "mobo_stamp_wave": development, the wave whose first lane takes the gradient chain's stamps
 extern int g_opt_mobo_full_chain;      // "mobo_full_chain": testing, the search without log_alpha on the full (sum + max) chain kernel
 extern int g_opt_conv_narrow_ft;      // "conv_narrow_ft": testing, frame tiles (8, 4, 2) per workgroup of the narrow conv kernel (0: the plan's choice)
+extern int g_opt_conv_no_ring;        // "conv_no_ring": A-B / testing, a k = 1 layer with many input chunks stages them all at once (conv_narrow_kernel)
 extern int g_opt_maxpath_no_optimistic_mask;   // "maxpath_no_optimistic_mask": A-B / testing, the strict mask is verified by a pass in front of the search, not by the zero workgroups beside it
 extern int g_opt_maxpath_no_mask_verify;   // "maxpath_no_mask_verify": A-B / testing, a strict mask is always multiplied in (no verification pass)
 extern int g_opt_maxpath_zero_blocks;      // "maxpath_zero_blocks": development, zero workgroups of the two-workgroup search launch (0: all idle CUs)

@@ -594,6 +594,78 @@ __global__ __launch_bounds__(512) void conv_narrow_kernel(ConvGemmParams p) {
     else       cg_store_f32<NT, FT>(p, acc, b, NT * wave, f0, lane);
 }
 
+// ---- a narrow k = 1 layer with MANY input chunks (the text stack's 1024 -> 80 projection: 32 chunks) ----
+// conv_narrow_kernel stages ALL chunks before its first MFMA: 128 KB for a 32-frame tile -- one workgroup a CU, six
+// waves, staging and arithmetic one after the other (30 us for 52 MB at C3: 1.7 TB/s; this form: 17 us).  Here the chunks come in GROUPS of
+// CNR_G through CNR_NB buffers of LDS (64 KB: two workgroups a CU): a loader wave keeps three groups in flight by LDS-DMA
+// and counts them in (vmcnt retires in order, and nothing else of that wave is in flight), the compute waves' only
+// loads are their weight rings (whose counted waits stay exact), one raw s_barrier per group: "group g has landed" and
+// "group g - 1 has been read" in one (the loader refills that buffer right behind it).  A group is CNR_G steps = one
+// turn of the four-step weight ring.
+constexpr int CNR_G = 4, CNR_NB = 4;
+static_assert(CNR_G == CN_RING, "a group of chunks is one turn of the weight ring (k = 1: a step per chunk)");
+
+template <int FT, int NT, bool SPLIT>
+__global__ __launch_bounds__(64 * 9) void conv_narrow_ring_kernel(ConvGemmParams p) {
+    constexpr int LROW = cg_lrow(1, FT), CHSLOT = 8 * LROW;
+    constexpr int GB = CNR_G * CHSLOT * 16;                      // bytes of a group in LDS
+    constexpr int PG = GB / 1024;                                // its 1 KB LDS-DMA pieces
+    constexpr int W2 = 2 * PG < 63 ? 2 * PG : 63;                // (the counter's field has 6 bits: a wait for one piece more than needed)
+    extern __shared__ __attribute__((aligned(16))) unsigned char cg_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (int)(blockDim.x >> 6) - 1;                   // compute waves; wave nw is the loader
+    const int bx = (int)(blockIdx.x % (unsigned)p.nx), b = (int)(blockIdx.x / (unsigned)p.nx);
+    const int f0 = bx * 16 * FT;
+    const int ng = p.nch / CNR_G;                                // (the host takes this form for whole groups only)
+    if (wave == nw) {
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)cg_smem;
+        const unsigned char *xbase = reinterpret_cast<const unsigned char *>(p.xs + (size_t)b * p.nch * 4 * p.S);
+        auto issue = [&](int g) {
+#pragma unroll
+            for (int q = 0; q < PG; ++q) {
+                const int i = 64 * (g * PG + q) + lane;          // cn_stage_all's piece g * PG + q
+                const int c = i / CHSLOT, r = i - c * CHSLOT;
+                const int plane = r / (4 * LROW), qq = (r / LROW) & 3, sl = r % LROW;
+                const unsigned voff = (unsigned)(((size_t)plane * p.xs_plane + ((size_t)c * 4 + qq) * p.S + f0 + sl) * 16);
+                cg_dma16(lds0 + (unsigned)(g % CNR_NB) * GB + (unsigned)q * 1024u, voff, xbase);
+            }
+        };
+        for (int g = 0; g < CNR_NB - 1 && g < ng; ++g) issue(g);
+        for (int g = 0; g < ng; ++g) {
+            const int last = g + CNR_NB - 2 < ng - 1 ? g + CNR_NB - 2 : ng - 1;     // the youngest group in flight
+            const int later = last - g;                                             // uniform: 0 .. CNR_NB - 2
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W2) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                        // group g is in LDS; group g - 1's buffer has been read
+            if (g + CNR_NB - 1 < ng) issue(g + CNR_NB - 1);      // ... and is refilled
+        }
+        return;
+    }
+    static_assert(CNR_NB - 2 == 2, "the loader's three wait cases");
+    CnRing<NT> R;
+    R.init(p.wp, p.cpad, p.nch, wave, lane, 0);                  // (no rotation: the groups arrive in order)
+    R.prime();
+    cg_f32x4 acc[NT][FT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int n = 0; n < FT; ++n) acc[a][n] = cg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < ng; ++g) {
+        __builtin_amdgcn_s_barrier();
+        // cn_step addresses chunk c at xl + c * CHSLOT * 16: chunk CNR_G * g + i sits in buffer g % CNR_NB at i
+        const unsigned char *xl = cg_smem + (size_t)(g % CNR_NB) * GB - (size_t)g * GB;
+        cg_static_for<0, CN_RING>([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            cn_step<1, LROW, FT, NT, CN_RING, SPLIT, I>(R, xl, CNR_G * g + I, lane, acc);
+        });
+    }
+    R.template drain<0>();
+    if (SPLIT) cg_store_split<NT, FT>(p, acc, b, NT * wave, f0, lane);
+    else       cg_store_f32<NT, FT>(p, acc, b, NT * wave, f0, lane);
+}
+
 // ---- a run of narrow layers in ONE kernel (the mel encoder: 80 -> 160 k=3, 160 -> 80, 80 -> 80) ----
 // Layers after the first have k = 1, so a frame tile of layer l+1 needs exactly the same frames of layer l: the
 // workgroup keeps its tile on the CU.  Layer l's epilogue writes the split image of layer l+1's input into a second LDS
@@ -769,6 +841,15 @@ static int launch_conv_narrow(const ConvGemmParams &p, int nw, hipStream_t s) {
     ALIGNER_HIP_CHECK(hipGetLastError());
     return ALIGNER_OK;
 }
+template <int FT, int NT, bool SPLIT>
+static int launch_conv_narrow_ring(const ConvGemmParams &p, int nw, hipStream_t s) {
+    constexpr size_t lds = (size_t)CNR_NB * CNR_G * 8 * cg_lrow(1, FT) * 16;
+    auto kern = conv_narrow_ring_kernel<FT, NT, SPLIT>;
+    ALIGNER_HIP_CHECK(ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.nx * (unsigned)p.B), dim3(64 * (nw + 1)), lds, s, p);   // + the loader wave
+    ALIGNER_HIP_CHECK(hipGetLastError());
+    return ALIGNER_OK;
+}
 template <int KT0, int FT, int N0, int N1, int N2>
 static int launch_conv_fused(const ConvFusedParams &p, int nw, int B, size_t lds, hipStream_t s) {
     auto kern = conv_narrow_fused_kernel<KT0, FT, N0, N1, N2>;
@@ -844,6 +925,14 @@ static int conv_launch(const ConvPlan &P, ConvGemmParams &p, int K, bool split, 
         if (K == 1) return P.FT == 13 ? CG_W(1, 13) : CG_W(1, 8);
         if (K == 3) return P.FT == 13 ? CG_W(3, 13) : CG_W(3, 8);
         return P.FT == 13 ? CG_W(5, 13) : CG_W(5, 8);
+    }
+    // many chunks of a split image into a k = 1 layer: the group-ring form (conv_narrow_ring_kernel)
+    if (K == 1 && P.FT == 2 && !p.xf && p.nch >= 4 * CNR_G && p.nch % CNR_G == 0 && P.nw <= 8 && !g_opt_conv_no_ring) {
+        // (fp32 epilogue: a wave whose 16 or 32 channels are all padding has nothing to store -- and no weights to stream:
+        // 1024 -> 80 with five compute waves 17.0 us, with the sixth 18.1.  64-frame tiles, one workgroup a CU: 21.8 us)
+        const int nw = split ? P.nw : (p.Cout + 16 * P.NT - 1) / (16 * P.NT);
+        if (P.NT == 2) return split ? launch_conv_narrow_ring<2, 2, true>(p, nw, s) : launch_conv_narrow_ring<2, 2, false>(p, nw, s);
+        return split ? launch_conv_narrow_ring<2, 1, true>(p, nw, s) : launch_conv_narrow_ring<2, 1, false>(p, nw, s);
     }
     return P.NT == 2 ? CG_NK(2) : CG_NK(1);
 #undef CG_W

@@ -477,7 +477,7 @@ def run_c3(args, world: int):
     it = 20
     f1 = 2.0 * Bc * Tx * Ct * 2 * Ct * 3
     stages = {
-        "text encoder, whole stack in one call (split pass + conv_gemm_kernel 512->1024 k3 + conv_narrow_kernel 1024->80 k1)": (event_time_us(lambda: aligner_amd.softattn.encode(text, params.key_proj), it, dev), f1 + 2.0 * Bc * Tx * 2 * Ct * Ca),
+        "text encoder, whole stack in one call (split pass + conv_gemm_kernel 512->1024 k3 + conv_narrow_ring_kernel 1024->80 k1)": (event_time_us(lambda: aligner_amd.softattn.encode(text, params.key_proj), it, dev), f1 + 2.0 * Bc * Tx * 2 * Ct * Ca),
         "text encoder conv 512->1024 k3 alone (split pass + conv_gemm_kernel, fp32 out)": (event_time_us(lambda: aligner_amd.softattn.conv1d(text, *params.key_proj[0], relu=True), it, dev), f1),
         "text encoder conv 1024->80 k1 alone (conv_narrow_kernel, fp32 input staged and split in the kernel)": (event_time_us(lambda: aligner_amd.softattn.conv1d(k1, *params.key_proj[1]), it, dev), 2.0 * Bc * Tx * 2 * Ct * Ca),
         "mel encoder, whole stack in one call (conv_narrow_fused_kernel: fp32 input staged and split in the kernel, the three layers in one kernel)": (event_time_us(lambda: aligner_amd.softattn.encode(mel, params.query_proj), it, dev), 2.0 * Bc * Ty * (Cm * 2 * Cm * 3 + 2 * Cm * Cm + Cm * Ca)),

@@ -383,6 +383,8 @@ def test_narrow_conv_every_frame_tile(dev, ft):
     (3, 900, (80, 160, 80, 80), (3, 1, 1)),        # the mel encoder
     (2, 150, (40, 64, 48, 130, 20), (5, 3, 3, 1)), # consumers with k != 1: fp32 temporary + split pass between the layers
     (2, 77, (160, 300), (1,)),                     # one layer, 300 output channels (wide form, three output tiles)
+    (2, 77, (128, 512, 33), (3, 1)),               # 16 chunks into a k = 1 layer (the group-ring form), ragged frame tile, 33 channels
+    (5, 333, (128, 640, 160), (1, 1)),             # 20 chunks, 160 output channels (two tiles a wave), T % 32 != 0
 ])
 def test_conv_stack_one_call(dev, B, T, chans, ks):
     """aligner_conv_stack_f32 (encode()): the whole stack in one call, layers chained through split images, against the
@@ -409,6 +411,16 @@ def test_conv_stack_one_call(dev, B, T, chans, ks):
     for n, (w, b) in enumerate(dstack):
         y = aligner_amd.conv1d(y, w, b, relu=(n + 1 < len(dstack)))
     assert (got - y).abs().max().item() < 5e-5
+    # a k = 1 layer with many input chunks: chunks in groups through a ring of LDS buffers (conv_narrow_ring_kernel) /
+    # all staged at once (conv_narrow_kernel): the same sums in another order; each of them the same bits call after call
+    again = encode(x.to(dev), dstack)
+    assert torch.equal(again, got)
+    assert lib.aligner_debug_set_option(b"conv_no_ring", 1) == 0
+    try:
+        flat = encode(x.to(dev), dstack)
+    finally:
+        lib.aligner_debug_set_option(b"conv_no_ring", 0)
+    assert (got - flat).abs().max().item() < 5e-5
 
 
 def test_pipeline_similarity_then_dp(dev):
