@@ -70,9 +70,10 @@ def forward_sum(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, want_g
 class _ForwardSumLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logp, t_x, t_y, blank_logprob):
-        need = logp.requires_grad
+        need = ctx.needs_input_grad[0]
         loss, grad = forward_sum(logp.detach(), t_x, t_y, want_grad=need, blank_logprob=blank_logprob)
         ctx.save_for_backward(grad if need else None)
+        ctx.in_dtype = logp.dtype                   # (the kernels compute in fp32; a bf16 / fp16 logp gets its gradient back in its dtype)
         return loss
 
     @staticmethod
@@ -80,17 +81,24 @@ class _ForwardSumLoss(torch.autograd.Function):
         (grad,) = ctx.saved_tensors
         if grad is None or g_loss is None:
             return None, None, None, None
-        return grad * g_loss.to(grad.dtype).view(-1, 1, 1), None, None, None
+        return (grad * g_loss.to(grad.dtype).view(-1, 1, 1)).to(ctx.in_dtype), None, None, None
 
 
 def forward_sum_loss(logp: torch.Tensor, t_x: torch.Tensor, t_y: torch.Tensor, blank_logprob: Optional[float] = -1.0,
-                     reduction: str = "mean") -> torch.Tensor:
+                     reduction: str = "mean", zero_infinity: bool = False, length_normalize: bool = False) -> torch.Tensor:
     """The OTA aligner's ForwardSumLoss as an autograd function on the GPU kernels: forward_sum() with its gradient
     attached, so that `forward_sum_loss(logp, t_x, t_y).backward()` reaches whatever differentiable torch code produced
     `logp` (this package's `soft_attention()` kernel is forward-only: SURVEY 8 scopes the front end's forward pass).  One launch pair computes loss AND gradient in the forward pass (both sweeps side by side); backward()
-    only scales.  blank_logprob = -1.0: the published CTC form (None: the plain monotonic form).  reduction: "mean" over
-    the batch (the paper's code: per-utterance CTC losses averaged), "sum" or "none"."""
+    only scales.  blank_logprob = -1.0: the published CTC form (None: the plain monotonic form).  reduction: "mean" (a plain
+    mean over the batch), "sum" or "none".  The two switches of torch.nn.CTCLoss that published aligner code is usually
+    written with (neither the reference snapshot nor SNIPPETS.md holds that code: parity unpinned) are here as options, off
+    by default: zero_infinity -- an infeasible utterance (t_x > t_y: loss +inf) contributes 0 and no gradient instead of
+    making the batch loss +inf; length_normalize -- each utterance's loss is divided by its t_x (CTCLoss's own "mean")."""
     loss = _ForwardSumLoss.apply(logp, t_x, t_y, blank_logprob)
+    if zero_infinity:
+        loss = torch.where(torch.isinf(loss), torch.zeros_like(loss), loss)
+    if length_normalize:
+        loss = loss / torch.as_tensor(t_x).to(device=loss.device, dtype=loss.dtype).clamp_min(1)
     if reduction == "mean":
         return loss.mean()
     if reduction == "sum":

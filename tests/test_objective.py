@@ -428,3 +428,32 @@ def test_forward_sum_loss_is_differentiable_like_its_float64_restatement(dev, bl
     # no gradient asked for: the loss alone (one sweep)
     l2 = aligner_amd.forward_sum_loss(torch.log_softmax(z.detach(), dim=1), tx, ty, blank_logprob=blank, reduction="none")
     assert not l2.requires_grad and l2.shape == (B,)
+
+
+@gpu
+def test_forward_sum_loss_options_and_input_dtype(dev):
+    """forward_sum_loss's CTCLoss-style switches and a 16-bit input: an infeasible utterance (t_x > t_y) makes the plain batch
+    loss +inf and, with zero_infinity, contributes 0 and no gradient; length_normalize divides each loss by its t_x; a bf16
+    logp gets its gradient back as bf16 (the kernels compute in fp32)."""
+    import aligner_amd
+    rng = np.random.default_rng(8)
+    B, Tx, Ty = 3, 20, 48
+    z0 = torch.tensor(rng.standard_normal((B, Tx, Ty)), dtype=torch.float32, device=dev)
+    tx = torch.tensor([Tx, 12, 20], dtype=torch.int32)
+    ty = torch.tensor([Ty, 30, 10], dtype=torch.int32)           # the last one: 20 tokens on 10 frames
+    z = z0.clone().requires_grad_(True)
+    each = aligner_amd.forward_sum_loss(torch.log_softmax(z, dim=1), tx, ty, reduction="none")
+    assert bool(torch.isinf(each[2])) and bool(torch.isfinite(each[:2]).all())
+    assert bool(torch.isinf(aligner_amd.forward_sum_loss(torch.log_softmax(z, dim=1), tx, ty)))
+    safe = aligner_amd.forward_sum_loss(torch.log_softmax(z, dim=1), tx, ty, reduction="sum", zero_infinity=True)
+    assert abs(float(safe.detach()) - float(each[:2].detach().sum())) < 1e-3
+    safe.backward()
+    assert bool(torch.isfinite(z.grad).all()) and float(z.grad[2].abs().max()) == 0.0 and float(z.grad[0].abs().max()) > 0
+    norm = aligner_amd.forward_sum_loss(torch.log_softmax(z.detach(), dim=1), tx, ty, reduction="none", zero_infinity=True,
+                                        length_normalize=True)
+    assert torch.allclose(norm[:2].cpu(), (each[:2].detach().cpu() / tx[:2].float()), rtol=1e-6)
+    # 16-bit log-probs
+    zb = z0[:2].to(torch.bfloat16).requires_grad_(True)
+    lb = aligner_amd.forward_sum_loss(torch.log_softmax(zb.float(), dim=1).to(torch.bfloat16), tx[:2], ty[:2], reduction="sum")
+    lb.backward()
+    assert zb.grad.dtype == torch.bfloat16 and bool(torch.isfinite(zb.grad).all()) and float(zb.grad.abs().max()) > 0
