@@ -26,6 +26,7 @@ F_STREAM_PATH = 128
 F_ONE_CU = 256
 F_TWO_CUS = 512
 F_TEST_DROP_FIRST_HALF = 1024
+F_TEST_IMPATIENT_FIRST_HALF = 16384
 F_PATH_PREZEROED = 2048
 F_SEPARATE_EXPAND = 4096
 F_TEST_DROP_ZERO_REPORTS = 8192

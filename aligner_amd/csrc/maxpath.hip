@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
                 unsigned v;
                 int spins = 0;
                 while ((v = __hip_atomic_load(p.xwalk + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == XRING_EMPTY) {
-                    if (++spins > XRING_SPIN_LIMIT) {
+                    if (++spins > ((p.flags & ALIGNER_F_TEST_IMPATIENT_FIRST_HALF) ? 0 : XRING_SPIN_LIMIT)) {
                         unsigned expect = XRING_EMPTY;                   // give up -- unless the word arrives this instant
                         if (__hip_atomic_compare_exchange_strong(p.xwalk + b, &expect, XWALK_CANCEL, __ATOMIC_RELAXED,
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -1255,7 +1255,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
             }
             __syncthreads();
             const unsigned hv = (unsigned)*bcast;
-            if (hv >= XWALK_CANCEL) return;      // SOLO: the other half did everything; CANCEL: it will write the all-zero result
+            if (hv >= XWALK_CANCEL) return;      // SOLO: the other half did everything; CANCEL: it will, when it arrives (below)
             ALIGNER_STAMP(1);
             if (wave == 0) {
                 int x = RPW * NW - 1, e = (int)hv;                       // row 251 ends at the frame handed over
@@ -1307,26 +1307,40 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
                     const bool ok = x == -1 && e >= r0 - 1 &&
                                     __hip_atomic_compare_exchange_strong(p.xwalk + b, &expect, (unsigned)e, __ATOMIC_RELAXED,
                                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!ok) {
+                    // The first half has given up waiting (XWALK_CANCEL: the CUs were contended, e.g. by another stream's
+                    // kernels; it has set ALIGNER_ST_INTERNAL and left without storing anything): its decision words are in
+                    // the workspace all the same (xflag's acquire above), so this half walks every row itself -- a late
+                    // answer, not a lost one.
+                    const bool cancelled = !ok && expect == XWALK_CANCEL;
+                    if (!ok && !cancelled) {
                         if (expect == XRING_EMPTY)                       // (an inconsistent walk: cannot happen)
                             __hip_atomic_store(p.xwalk + b, XWALK_SOLO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         atomicOr(p.status, ALIGNER_ST_INTERNAL);
                     }
-                    *bcast = ok ? 1 : 0;
+                    *bcast = ok ? 1 : cancelled ? 2 : 0;
                 }
             }
             ALIGNER_STAMP(3);
             __syncthreads();
-            if (*bcast == 0) {                                           // the first half is not there: the defined failure
-                __syncthreads();
+            const int handed = *bcast;
+            __syncthreads();                                             // (everybody has read the word: its LDS may be reused)
+            if (handed == 0) {                                           // the defined failure
                 write_degenerate<MASKMODE, VT>(p, b, MODE_EMPTY, tx, ty, reinterpret_cast<int *>(smem));
                 return;
             }
-            for (int r = tx + tid; r <= p.Tx; r += NW * 128) startsL[r] = ty;
-            __syncthreads();
-            store_outputs(p, b, tx, ty, startsL, true, r0, -1, startsL[r0], -1);
-            ALIGNER_STAMP(5);
-            ALIGNER_STAMP(7);
+            if (handed == 1) {
+                for (int r = tx + tid; r <= p.Tx; r += NW * 128) startsL[r] = ty;
+                __syncthreads();
+                store_outputs(p, b, tx, ty, startsL, true, r0, -1, startsL[r0], -1);
+                ALIGNER_STAMP(5);
+                ALIGNER_STAMP(7);
+                return;
+            }
+            // handed == 2: the one-walker form, over both halves' words in the workspace (no non-finite score was seen:
+            // that was asked above).  (A call of its own rather than a fall-through to the one below: what that one
+            // needs would otherwise stay live in scalar registers across the generated walk above -- 64 of them spilled.)
+            __threadfence_block();
+            backtrack_and_store<(NW <= 4)>(p, b, tx, ty, smem);
             return;
         }
         if (p.split_walk && tid == 0) __hip_atomic_store(p.xwalk + b, XWALK_SOLO, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -109,6 +109,10 @@ extern "C" {
 #define ALIGNER_F_TEST_DROP_FIRST_HALF 1024 /* testing: in the two-workgroup form the first half of every utterance leaves
                                       without delivering, so the second gives up after its bounded wait: all-zero
                                       path, zero durations, ALIGNER_ST_INTERNAL -- the defined failure of that form */
+#define ALIGNER_F_TEST_IMPATIENT_FIRST_HALF 16384 /* testing: in the two-workgroup form the first half gives up waiting for the
+                                      backtrack's hand-over at once (as it would after its bounded wait on a contended
+                                      chip): ALIGNER_ST_INTERNAL is set, and the second half, finding that, walks
+                                      every row itself -- the answer is late, not lost */
 #define ALIGNER_F_TEST_DROP_ZERO_REPORTS 8192 /* testing: the zero workgroups of the one-launch dense path (above) write their
                                       zeros but never report, so every utterance's workgroup gives up after a (here
                                       shortened) bounded wait -- the defined failure of that form: no 1 in the path

@@ -783,6 +783,15 @@ def test_two_workgroups_first_half_never_delivers(dev):
     # and the next call is fine again
     p, _, _ = _hip(v, tx, ty, dev, cus_per_utterance=2)
     assert np.array_equal(p, want) and aligner_amd.read_status(dev) == 0
+    # A first half that gives up waiting for the backtrack's hand-over (a contended chip; here: at once, by the test flag)
+    # costs time, not the answer: the second half finds the cancelled word and walks every row itself.  The status word
+    # still says that a wait gave up.
+    p, tok, dur = _hip(v, tx, ty, dev, cus_per_utterance=2, _test_flags=_lib.F_TEST_IMPATIENT_FIRST_HALF)
+    assert np.array_equal(p, want) and np.array_equal(dur, want.sum(2))
+    st = aligner_amd.read_status(dev)
+    assert st in (0, _lib.ST_INTERNAL)          # (0: the hand-over was there before the first poll)
+    p, _, _ = _hip(v, tx, ty, dev, cus_per_utterance=2)
+    assert np.array_equal(p, want) and aligner_amd.read_status(dev) == 0
 
 
 def test_zero_workgroups_never_report_is_a_defined_failure(dev):
