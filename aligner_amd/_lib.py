@@ -59,6 +59,7 @@ SIGNATURES = {
                                  _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz,
                              _i, _i, _i, _f, _i, _vp]),
+    "aligner_maxpath_ld": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_forward": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
                                      _i, _i, _i, _f, _i, _vp]),
     "aligner_maxpath_forward_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz,
@@ -74,6 +75,7 @@ SIGNATURES = {
     "aligner_softattn_workspace_bytes": (_sz, [_i, _i, _i]),
     "aligner_softattn": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
     "aligner_softattn_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
+    "aligner_softattn_ld": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _i, _i, _i, _i, _f, _i, _vp]),
     "aligner_conv1d_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "aligner_conv1d_prepared_bytes": (_sz, [_i, _i, _i]),
     "aligner_conv1d_prepare_f32": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp]),
@@ -94,6 +96,9 @@ SIGNATURES = {
     "aligner_boundary_search_backward": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "aligner_regulate_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
+
+
+EINVAL, EDOM, ENOSPC = -22, -33, -28     # ALIGNER_E* (include/aligner_amd.h)
 
 
 class AlignerError(RuntimeError):

@@ -78,6 +78,8 @@ struct MaxpathParams {
     int         *mflag;     // [B][MV_CHUNKS] nonzero = that piece of the utterance's mask is not all ones inside [0,t_x) x [0,t_y)
     int          verify;    // the launch's zero workgroups also verify p.mask (strict mask, optimistic search: see the kernel)
     int          redo;      // MASKMODE 1: only the utterances a verdict in mflag names, their earlier ones erased first
+    int          ldv;       // row pitch of `value` (and of `mask`) in elements: Ty, or more when the producer padded its rows to whole
+                            // 128-byte lines (aligner_maxpath_ld)
     int B, Tx, Ty, NT, ROWS;
     int WT;                 // tiles per backtrack window when the words live in global memory
     int bits_in_lds;        // pipelined kernel: decision words stay in LDS
@@ -300,13 +302,13 @@ __device__ __forceinline__ void write_degenerate(const MaxpathParams &p, int b, 
     for (int x = tid; x <= p.Tx; x += nthreads) startsL[x] = (mode == MODE_COMPAT && x >= tx) ? ty : 0;
     __syncthreads();
     if (mode == MODE_COMPAT && tid == 0) {
-        const size_t ub = (size_t)b * p.Tx * p.Ty;
+        const size_t ub = (size_t)b * p.Tx * p.ldv;
         int index = tx - 1;
         for (int y = ty - 1; y >= 1; --y) {
             if (index == 0) break;
             bool up = (index == y);
             if (!up) {
-                const size_t ia = ub + (size_t)index * p.Ty + (y - 1), ic = ub + (size_t)(index - 1) * p.Ty + (y - 1);
+                const size_t ia = ub + (size_t)index * p.ldv + (y - 1), ic = ub + (size_t)(index - 1) * p.ldv + (y - 1);
                 float a = load_score<VT>(p.value, ia), c = load_score<VT>(p.value, ic);
                 if (MASKMODE == 1) {
                     a = mul_in_dtype<VT>(a, load_score<VT>(p.mask, ia));
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
 
     float *qcol = reinterpret_cast<float *>(smem);   // [2][256*R + 1], index x+1
     const int QLD = 256 * R + 1;
-    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const size_t ubase = (size_t)b * p.Tx * p.ldv;
     unsigned *gbits = p.bits + (size_t)b * p.NT * p.ROWS;
 
     float q[R];
@@ -627,12 +629,12 @@ __global__ __launch_bounds__(256) void maxpath_generic_kernel(MaxpathParams p) {
                 const float up = src[x];                           // Q[x-1,y-1] (or the x==0 edge)
                 const float cur = (x == y) ? p.neg : q[r];         // core.pyx:19-22
                 const bool adv = up > cur;                         // core.c:19384
-                float v = load_score<VT>(p.value, ubase + (size_t)x * p.Ty + y);
-                if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.Ty + y));
+                float v = load_score<VT>(p.value, ubase + (size_t)x * p.ldv + y);
+                if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.ldv + y));
                 q[r] = (adv ? up : cur) + v;                       // core.pyx:30
                 // the reference overwrites value[x, y] with Q inside its band only (core.pyx:18,30); cells outside
                 // it keep their scores.  In place: this thread alone reads and writes the cell.
-                if (p.qout && x <= y && x >= tx + y - ty) p.qout[ubase + (size_t)x * p.Ty + y] = q[r];
+                if (p.qout && x <= y && x >= tx + y - ty) p.qout[ubase + (size_t)x * p.ldv + y] = q[r];
                 // backtrack predicate (core.pyx:34): the diagonal move is forced whatever the scores
                 bits[r] = (bits[r] << 1) | ((adv || x == y) ? 1u : 0u);
                 dst[x + 1] = q[r];
@@ -761,7 +763,7 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
     const int tid = threadIdx.x, nthreads = blockDim.x;
     float *qcol = reinterpret_cast<float *>(smem);            // [2][nthreads + 1], index x+1
     const int QLD = nthreads + 1;
-    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const size_t ubase = (size_t)b * p.Tx * p.ldv;
     const int x = tid;                                        // tx <= 63*NW < nthreads
     const int slot = x;
     unsigned *gw = p.bits + (size_t)b * p.NT * p.ROWS + slot;
@@ -779,8 +781,8 @@ __device__ __forceinline__ void exact_fallback_sweep(const MaxpathParams &p, int
             const float up = src[x];
             const float cur = (x == y) ? p.neg : q;             // core.pyx:19-22
             const bool adv = up > cur;                          // core.c:19384
-            float v = load_score<VT>(p.value, ubase + (size_t)x * p.Ty + y);
-            if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.Ty + y));
+            float v = load_score<VT>(p.value, ubase + (size_t)x * p.ldv + y);
+            if (MASKMODE == 1) v = mul_in_dtype<VT>(v, load_score<VT>(p.mask, ubase + (size_t)x * p.ldv + y));
             q = (adv ? up : cur) + v;                           // core.pyx:30
             bits = (bits << 1) | ((adv || x == y) ? 1u : 0u);   // core.pyx:34
             dst[x + 1] = q;
@@ -836,6 +838,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ldv = PAIR ? p.Ty : p.ldv;            // (the two-workgroup form is out of scalar registers: contiguous scores only, forward_impl)
     const int half = PAIR ? (int)(blk >= p.B) : 0;
     const int b = PAIR ? blk - half * p.B : blk;
     int tx, ty;
@@ -859,7 +862,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
     unsigned *bitsL = reinterpret_cast<unsigned *>(smem + p.lds_bits_off);   // [NT][ROWS+1] when in LDS
     const int RPB = row_pitch(p.ROWS);
     const int ntb = (ty + TC - 1) / TC;
-    const size_t ubase = (size_t)b * p.Tx * p.Ty;
+    const size_t ubase = (size_t)b * p.Tx * ldv;
     const int nw_act = (tx + RPW - 1) / RPW;                    // waves that own at least one real row
 
     // wave 0's ghost lane replays "row -1": max_neg_val for every frame (core.pyx:27)
@@ -1054,11 +1057,11 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
                         // by its last row: they are never read by the DP and must not trip the finiteness scan
                         int r = RPW * gw + 8 * k + rr - 1;
                         r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
-                        rowoff[k] = (unsigned)r * (unsigned)p.Ty;
+                        rowoff[k] = (unsigned)r * (unsigned)ldv;
                     }
                     float4 buf[DEPTH][8];
                     // VEC: buffer loads, per-lane byte offsets fixed for the whole sweep + a scalar tile offset
-                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 4u;
+                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)ldv * 4u;
                     const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
                     const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(MASKMODE == 1 ? mb : ub, ubytes);
                     unsigned voff[8];
@@ -1131,7 +1134,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
                     float *mytiles = tiles + w * 2 * 64 * TILE_LD + rr * TILE_LD + 8 * cg;
                     const unsigned short *ub = static_cast<const unsigned short *>(p.value) + ubase;
                     const unsigned short *mb = (MASKMODE == 1) ? static_cast<const unsigned short *>(p.mask) + ubase : ub;
-                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)p.Ty * 2u;
+                    const unsigned ubytes = (unsigned)p.Tx * (unsigned)ldv * 2u;
                     const __amdgpu_buffer_rsrc_t urs = utterance_rsrc(ub, ubytes);
                     const __amdgpu_buffer_rsrc_t mrs = utterance_rsrc(mb, ubytes);
                     unsigned voff[4];
@@ -1141,7 +1144,7 @@ __device__ __forceinline__ void maxpath_pipelined_body(const MaxpathParams &p, c
                         // are replaced by its last row (never read by the DP, must not trip the finiteness scan)
                         int r = RPW * gw + 16 * k + rr - 1;
                         r = r < 0 ? 0 : (r > tx - 1 ? tx - 1 : r);
-                        voff[k] = ((unsigned)r * (unsigned)p.Ty + 8u * (unsigned)cg) * 2u;
+                        voff[k] = ((unsigned)r * (unsigned)ldv + 8u * (unsigned)cg) * 2u;
                     }
                     u32x4r buf[DEPTH][4], mbuf[MASKMODE == 1 ? DEPTH : 1][4];
                     auto issue = [&](int d, int t) {
@@ -1800,7 +1803,8 @@ static void set_path_ones(MaxpathParams &p, void *path, int path_dtype) {
 static int forward_impl(const void *value, int value_dtype, const void *mask, int mask_dtype, const int32_t *t_xs,
                         const int32_t *t_ys, int32_t *tok_out, int32_t *dur_out, void *ws,
                         size_t ws_bytes, int B, int Tx, int Ty, float neg, int flags, hipStream_t s,
-                        void *path_out = nullptr, int path_dtype = 0, bool path_is_zero = false, bool *path_done = nullptr) {
+                        void *path_out = nullptr, int path_dtype = 0, bool path_is_zero = false, bool *path_done = nullptr,
+                        int ldv = 0) {
     // path_out: the dense path this launch may finish itself -- its ones always (path_is_zero: the caller's zeros,
     // ALIGNER_F_PATH_PREZEROED), its zeros too where the pipelined kernel runs with zero workgroups; *path_done says
     // whether it did (otherwise the caller launches expand)
@@ -1820,6 +1824,13 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     if ((flags & ALIGNER_F_STRICT_MASK) && mask_dtype != value_dtype)
         return fail(ALIGNER_EINVAL, "strict mask must have the scores' dtype (mask %d, value %d): the product is "
                                     "rounded in that dtype like torch's value * mask", mask_dtype, value_dtype);
+    // ldv: the scores' row pitch (aligner_maxpath_ld).  A pitch of its own comes with lengths and without a mask: it is
+    // the layout of the pipeline's own intermediate, not of the reference's tensors
+    if (ldv == 0) ldv = Ty;
+    if (ldv < Ty) return fail(ALIGNER_EINVAL, "ld_value=%d < Ty=%d", ldv, Ty);
+    if (ldv != Ty && (mask || !t_xs || !t_ys || (flags & ALIGNER_F_WRITE_Q)))
+        return fail(ALIGNER_EINVAL, "a row pitch of its own (ld_value=%d, Ty=%d) takes lengths, no mask and no ALIGNER_F_WRITE_Q", ldv, Ty);
+    if ((size_t)Tx * (size_t)ldv >= (1ull << 31)) return fail(ALIGNER_EDOM, "Tx*ld_value=%zu exceeds 2^31", (size_t)Tx * ldv);
     if (B == 0) return ALIGNER_OK;
     const WsLayout L = ws_layout(B, Tx, Ty);
     if (ws_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", ws_bytes, L.total);
@@ -1874,7 +1885,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     p.bits = reinterpret_cast<unsigned *>(wsb + L.bits_off);
     p.status = reinterpret_cast<int *>(wsb + L.status_off);
     p.mflag = reinterpret_cast<int *>(wsb + L.mflag_off);
-    p.verify = 0; p.redo = 0;
+    p.verify = 0; p.redo = 0; p.ldv = ldv;
     p.B = B; p.Tx = Tx; p.Ty = Ty; p.NT = L.NT; p.ROWS = L.ROWS;
     p.neg = neg; p.flags = flags;
     p.bits_in_lds = 0; p.lds_bits_off = 0; p.lds_prev_off = 0;
@@ -1903,9 +1914,9 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     const size_t lds_max = (size_t)lds_limit();
     // vec: 16-byte loads; the pipelined kernel's loaders address an utterance with 32-bit byte offsets
     const int per16 = vt == VT_F32 ? 4 : 8;                      // scores per 16-byte load
-    const bool vec = (Ty % per16 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
+    const bool vec = (Ty % per16 == 0) && (ldv % per16 == 0) && ((reinterpret_cast<uintptr_t>(value) & 15) == 0) &&
                      (!maskmode || (reinterpret_cast<uintptr_t>(mask) & 15) == 0) &&
-                     (size_t)Tx * (size_t)Ty * 4 < (1ull << 31);
+                     (size_t)Tx * (size_t)ldv * 4 < (1ull << 31);
 
     const int nw_need = (Tx + RPW - 1) / RPW;
     // Long text (5..8 waves of rows) on a batch that leaves CUs idle: two workgroups per utterance, each the
@@ -1915,7 +1926,7 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
     // workgroups / one): [8,500,4000] 106 / 134 us, [8,500,2048] 68 / 76, [8,500,1536] 59 / 63, [8,500,1024] 50 / 50,
     // [8,300,1536] 49 / 48; [16,400,2000] 65 / 75, [32,400,2000] 68 / 75, [64,400,2000] 74 / 76, [64,500,2048] 79 / 79:
     // taken from 56 tiles on, for batches of at most an eighth of the CU count.
-    if (!(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_ONE_CU)) && nw_need > 4 && nw_need <= 8 && vec &&
+    if (!(flags & (ALIGNER_F_FORCE_GENERIC | ALIGNER_F_ONE_CU)) && nw_need > 4 && nw_need <= 8 && vec && ldv == Ty &&
         2 * B <= device_cu_count() &&      // both halves of every utterance resident at once (see the kernel)
         ((flags & ALIGNER_F_TWO_CUS) || (8 * B <= device_cu_count() && L.NT >= 56))) {
         const size_t fwd = align_up(((size_t)4 * (2 * 64 * TILE_LD + RING_T * RING_LD) + RING_T * RING_LD) * 4 + 16, 16);
@@ -2249,6 +2260,20 @@ int aligner_maxpath(const void *value, int value_dtype, const void *mask, int ma
     bool path_done = false;
     int rc = forward_impl(value, value_dtype, mask, mask_dtype, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty,
                           max_neg_val, flags, static_cast<hipStream_t>(stream), path_out, path_dtype, prez, &path_done);
+    if (rc || !path_out || B == 0 || path_done) return rc;
+    return aligner_maxpath_expand_ex(ws, path_out, path_dtype, B, Tx, Ty, flags, stream);
+}
+
+int aligner_maxpath_ld(const void *value, int value_dtype, int ld_value, const int32_t *t_xs, const int32_t *t_ys,
+                       void *path_out, int path_dtype, int32_t *tok_out, int32_t *dur_out, void *ws, size_t ws_bytes, int B,
+                       int Tx, int Ty, float max_neg_val, int flags, void *stream) {
+    if (path_out && dtype_size(path_dtype) == 0)
+        return fail(ALIGNER_EINVAL, "path dtype %d not supported", path_dtype);
+    if (flags & ALIGNER_F_STRICT_MASK) return fail(ALIGNER_EINVAL, "aligner_maxpath_ld takes no mask");
+    const bool prez = path_out && (flags & ALIGNER_F_PATH_PREZEROED);
+    bool path_done = false;
+    int rc = forward_impl(value, value_dtype, nullptr, 0, t_xs, t_ys, tok_out, dur_out, ws, ws_bytes, B, Tx, Ty, max_neg_val,
+                          flags, static_cast<hipStream_t>(stream), path_out, path_dtype, prez, &path_done, ld_value);
     if (rc || !path_out || B == 0 || path_done) return rc;
     return aligner_maxpath_expand_ex(ws, path_out, path_dtype, B, Tx, Ty, flags, stream);
 }

@@ -69,6 +69,7 @@ struct SoftAttnParams {
     int sim;
     int out16;              // logp is written as bf16 (round to nearest even)
     int pair;               // row-group form on a small batch: 2 or 4 waves share a 32-frame strip, each a part of the row tiles (0: one wave)
+    int ldo;                // row pitch of logp in elements (>= Ty; the row-tile form only: aligner_softattn_ld)
 };
 
 constexpr int SA_WAVES = 8;                       // waves per workgroup: 8 x 32 = 256 mel frames share one staged text operand
@@ -1076,13 +1077,13 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
     // hardware, a lane whose frame does not exist carries an offset beyond any block (softattn_kernel's store path)
     constexpr unsigned esz = OUT16 ? 2u : 4u;
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<unsigned char *>(p.logp) + (size_t)b * p.Tx * p.Ty * esz, 0, (unsigned)p.Tx * (unsigned)p.Ty * esz,
+        reinterpret_cast<unsigned char *>(p.logp) + (size_t)b * p.Tx * p.ldo * esz, 0, (unsigned)p.Tx * (unsigned)p.ldo * esz,
         0x00020000);
-    const unsigned row_bytes = (unsigned)p.Ty * esz;
+    const unsigned row_bytes = (unsigned)p.ldo * esz;
     const unsigned tile_bytes = (unsigned)(32 * tile) * row_bytes;
     auto lane_byte_of = [&](int j) {
         const int col = f0 + 32 * j + l31;
-        return col < p.Ty ? (unsigned)(4 * half * p.Ty + col) * esz : 0x80000000u;
+        return col < p.Ty ? (unsigned)(4 * half * p.ldo + col) * esz : 0x80000000u;
     };
     auto out_store = [&](float v, unsigned lane_byte, int e) {
         const int iu = (e & 3) + 8 * (e >> 2);
@@ -2061,15 +2062,23 @@ int aligner_softattn_f32(const float *keys, const float *queries, const int32_t 
 int aligner_softattn(const float *keys, const float *queries, const int32_t *t_xs, const float *prior,
                      void *logp_out, int logp_dtype, float *soft_out, void *workspace, size_t workspace_bytes, int B,
                      int C, int Tx, int Ty, float temperature, int sim, void *stream) {
+    return aligner_softattn_ld(keys, queries, t_xs, prior, logp_out, logp_dtype, Ty, soft_out, workspace, workspace_bytes, B, C,
+                               Tx, Ty, temperature, sim, stream);
+}
+
+int aligner_softattn_ld(const float *keys, const float *queries, const int32_t *t_xs, const float *prior,
+                        void *logp_out, int logp_dtype, int ld_logp, float *soft_out, void *workspace, size_t workspace_bytes,
+                        int B, int C, int Tx, int Ty, float temperature, int sim, void *stream) {
     if (!keys || !queries || !logp_out || !workspace) return fail(ALIGNER_EINVAL, "null pointer");
+    if (ld_logp < Ty) return fail(ALIGNER_EINVAL, "ld_logp=%d < Ty=%d", ld_logp, Ty);
     if (logp_dtype != ALIGNER_DT_F32 && logp_dtype != ALIGNER_DT_BF16)
         return fail(ALIGNER_EINVAL, "logp dtype %d not supported (F32 or BF16)", logp_dtype);
     if (B < 0 || C < 1 || Tx < 1 || Ty < 1) return fail(ALIGNER_EINVAL, "bad shape B=%d C=%d Tx=%d Ty=%d", B, C, Tx, Ty);
     if (sim != ALIGNER_SIM_L2 && sim != ALIGNER_SIM_DOT) return fail(ALIGNER_EINVAL, "bad sim %d", sim);
     if (C > 256) return fail(ALIGNER_EDOM, "C=%d exceeds 256 attention channels", C);
     if (B > 65535) return fail(ALIGNER_EDOM, "B=%d too large", B);
-    if ((size_t)Tx * (size_t)Ty >= (1ull << 29))          // an utterance's block is one buffer resource (32-bit offsets)
-        return fail(ALIGNER_EDOM, "Tx*Ty=%zu exceeds 2^29", (size_t)Tx * Ty);
+    if ((size_t)Tx * (size_t)ld_logp >= (1ull << 29))     // an utterance's block is one buffer resource (32-bit offsets)
+        return fail(ALIGNER_EDOM, "Tx*ld=%zu exceeds 2^29", (size_t)Tx * ld_logp);
     if (B == 0) return ALIGNER_OK;
     const SaLayout L = sa_layout(B, C, Tx);
     if (workspace_bytes < L.total) return fail(ALIGNER_ENOSPC, "workspace %zu < %zu bytes", workspace_bytes, L.total);
@@ -2077,8 +2086,19 @@ int aligner_softattn(const float *keys, const float *queries, const int32_t *t_x
     SoftAttnParams p{keys, queries, t_xs, prior, static_cast<float *>(logp_out), soft_out,
                      reinterpret_cast<const uint4 *>(ws + L.hi_off), reinterpret_cast<const uint4 *>(ws + L.lo_off),
                      reinterpret_cast<const float *>(ws + L.kn_off), L.RT, g_debug_stamps, B, C, Tx, Ty, temperature,
-                     sim, logp_dtype == ALIGNER_DT_BF16 ? 1 : 0};
+                     sim, logp_dtype == ALIGNER_DT_BF16 ? 1 : 0, 0, ld_logp};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // a row pitch of its own (rows that start on a 128-byte line: see aligner_amd.h) is the row-tile form's
+    const bool rt_form = L.KS <= 8 && L.RT <= 7 && C == 16 * L.KS && (Ty & 3) == 0 && !prior && !soft_out && !g_opt_softattn_strips &&
+                         (reinterpret_cast<uintptr_t>(queries) & 15) == 0;
+    if (ld_logp != Ty) {
+        const bool sharp0 = (sim == ALIGNER_SIM_L2) ? temperature > 0.002f : temperature > 0.2f;
+        if (!rt_form || sharp0 || g_opt_softattn_exact)
+            return fail(ALIGNER_EDOM, "ld_logp != Ty needs the row-tile form (Tx <= 224, C = 80 or 128, Ty %% 4 == 0, no prior / soft "
+                                      "output, a temperature the bf16x3 products hold)");
+        if ((ld_logp * (logp_dtype == ALIGNER_DT_BF16 ? 2 : 4)) % 16 != 0)
+            return fail(ALIGNER_EINVAL, "ld_logp=%d: rows must start on 16-byte boundaries", ld_logp);
+    }
     // sharp temperatures multiply the bf16x3 product error past the 1e-4 bound: exact fp32 products instead
     // (rule and reasoning: softattn_exact_kernel)
     const bool sharp = (sim == ALIGNER_SIM_L2) ? temperature > 0.002f : temperature > 0.2f;
@@ -2093,8 +2113,7 @@ int aligner_softattn(const float *keys, const float *queries, const int32_t *t_x
         return fail(ALIGNER_EDOM, "soft output with a prior needs Tx <= %d", 32 * G);
     // the row-tile form (softattn_rt_kernel): one row group, no channel padding (the loader's LDS-DMA reads whole
     // 8-channel pieces), frames in aligned quads, log-probs only
-    if (!multi && L.KS <= 8 && C == 16 * L.KS && (Ty & 3) == 0 && !prior && !soft_out && !g_opt_softattn_strips &&
-        (reinterpret_cast<uintptr_t>(queries) & 15) == 0) {
+    if (!multi && rt_form) {
         if (L.KS == 5) return p.out16 ? launch_softattn_rt<5, 7, true>(p, s) : launch_softattn_rt<5, 7, false>(p, s);
         return p.out16 ? launch_softattn_rt<8, 7, true>(p, s) : launch_softattn_rt<8, 7, false>(p, s);
     }

@@ -110,7 +110,14 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
             strict_mask = False
         if v.dtype not in _SCORE_DTYPES:
             v = v.float()                   # fp64 / integer scores: the reference's astype(np.float32)
-        if not v.is_contiguous():
+        # a row pitch of its own (softattn.pitched_logp(): rows on whole 128-byte lines) is read as it is -- with lengths,
+        # without a mask; anything else that is not contiguous is copied
+        ld = Ty
+        ldc = int(v.stride(1)) if Tx > 1 else int(v.stride(0))
+        if (not v.is_contiguous() and m is None and t_x is not None and t_y is not None and v.stride(2) == 1 and ldc >= Ty and
+                (B == 1 or v.stride(0) == Tx * ldc) and (ldc * v.element_size()) % 16 == 0):
+            ld = ldc
+        elif not v.is_contiguous():
             v = v.contiguous()
         if m is not None:
             if m.dtype not in (torch.float32, torch.bfloat16, torch.float16, torch.uint8, torch.bool, torch.int32):
@@ -157,9 +164,14 @@ def align(value: torch.Tensor, t_x: Optional[torch.Tensor] = None, t_y: Optional
                     (_lib.F_ONE_CU if cus_per_utterance == 1 else _lib.F_TWO_CUS if cus_per_utterance == 2 else 0) | \
                     (_lib.F_PATH_PREZEROED if (out_path_is_zero and out_path is not None) else 0) | \
                     int(_test_flags)
-            _lib.check(lib.aligner_maxpath(
-                v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
-                ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))
+            if ld != Ty:
+                _lib.check(lib.aligner_maxpath_ld(
+                    v.data_ptr(), _TORCH_TO_DT[v.dtype], ld, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
+                    ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))
+            else:
+                _lib.check(lib.aligner_maxpath(
+                    v.data_ptr(), _TORCH_TO_DT[v.dtype], _ptr(m), mdt, _ptr(t_x), _ptr(t_y), _ptr(path), pdt, _ptr(tok), _ptr(dur),
+                    ws.data_ptr(), ws.numel(), B, Tx, Ty, float(max_neg_val), flags, _stream_ptr(device)))
         else:
             for t in (path, tok, dur):
                 if t is not None:

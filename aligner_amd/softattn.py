@@ -118,8 +118,13 @@ def conv1d_raw(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
 def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optional[torch.Tensor] = None,
                    prior: Optional[torch.Tensor] = None, temperature: float = 0.0005, sim: str = "l2",
                    want_soft: bool = False, out: Optional[torch.Tensor] = None,
-                   logp_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                   logp_dtype: torch.dtype = torch.float32, pitched: bool = False
+                   ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """logp[b,i,j] (and optionally softmax over text of it) from encoded text/mel.
+
+    pitched: return the log-probs as a [B,T_text,T_mel] VIEW of a buffer whose rows start on whole 128-byte lines
+    (pitched_logp(): what align() reads fastest; not contiguous unless T_mel already is a multiple of 128 bytes) where
+    the kernel form has a row pitch of its own, contiguous otherwise.
 
     keys_enc [B,C,T_text], queries_enc [B,C,T_mel] fp32 (channel-major, as the conv
     encoders emit).  Rows i >= t_x[b] are masked to -inf.  logp_dtype torch.bfloat16 writes the log-probs as
@@ -141,21 +146,41 @@ def soft_attention(keys_enc: torch.Tensor, queries_enc: torch.Tensor, t_x: Optio
         logp_dtype = out.dtype
     if logp_dtype not in (torch.float32, torch.bfloat16):
         raise ValueError("logp_dtype must be torch.float32 or torch.bfloat16")
+    if out is None and pitched and prior is None and not want_soft and Tx <= 224 and C in (80, 128) and Ty % 4 == 0:
+        try:
+            return soft_attention(k, q, t_x=t_x, temperature=temperature, sim=sim, out=pitched_logp(B, Tx, Ty, dev, logp_dtype))
+        except _lib.AlignerError as e:          # (a sharp temperature: the exact-product kernel has no row pitch)
+            if e.code != _lib.EDOM:
+                raise
     logp = out if out is not None else torch.empty((B, Tx, Ty), dtype=logp_dtype, device=dev)
-    if tuple(logp.shape) != (B, Tx, Ty) or not logp.is_contiguous():
-        raise ValueError("out must be a contiguous [B,T_text,T_mel] tensor")
+    # `out` may carry a row pitch of its own (a view [:, :, :T_mel] of a [B,T_text,ld] buffer: pitched_logp())
+    ld = Ty
+    if tuple(logp.shape) == (B, Tx, Ty):
+        ld = int(logp.stride(1)) if Tx > 1 else int(logp.stride(0)) if B > 1 else Ty
+    if tuple(logp.shape) != (B, Tx, Ty) or logp.stride(2) != 1 or ld < Ty or (B > 1 and logp.stride(0) != Tx * ld):
+        raise ValueError("out must be a [B,T_text,T_mel] tensor, contiguous or with a row pitch (pitched_logp())")
     soft = torch.empty((B, Tx, Ty), dtype=torch.float32, device=dev) if want_soft else None
     simc = {"l2": _lib.SIM_L2, "dot": _lib.SIM_DOT}[sim]
     lib = _lib.load()
     with torch.cuda.device(dev):
         ws = _workspace(dev, lib.aligner_softattn_workspace_bytes(B, C, Tx))
-        _lib.check(lib.aligner_softattn(
+        _lib.check(lib.aligner_softattn_ld(
             k.data_ptr(), q.data_ptr(), None if t_x is None else t_x.data_ptr(),
             None if prior is None else prior.data_ptr(), logp.data_ptr(),
-            _lib.DT_BF16 if logp_dtype == torch.bfloat16 else _lib.DT_F32,
+            _lib.DT_BF16 if logp_dtype == torch.bfloat16 else _lib.DT_F32, ld,
             None if soft is None else soft.data_ptr(), ws.data_ptr(), ws.numel(),
             B, C, Tx, Ty, float(temperature), simc, _stream(dev)))
     return logp, soft
+
+
+def pitched_logp(B: int, T_text: int, T_mel: int, device, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """A [B,T_text,T_mel] tensor whose rows start on 128-byte lines (row pitch = T_mel rounded up to 128 bytes): the
+    pipeline's own intermediate between soft_attention(out=...) and align().  With T_mel = 1000 fp32 a row is 4000 bytes and
+    three quarters of the 128-byte runs the similarity kernel stores (and the search's loaders fetch) straddle two lines; at a
+    pitch of 1024 elements none does.  The extra columns are never touched."""
+    per = 128 // torch.empty((), dtype=dtype).element_size()
+    ld = (T_mel + per - 1) // per * per
+    return torch.empty((B, T_text, ld), dtype=dtype, device=device)[:, :, :T_mel]
 
 
 @dataclass
@@ -218,8 +243,8 @@ def encode(x: torch.Tensor, stack: List[Tuple[torch.Tensor, torch.Tensor]]) -> t
 
 def alignment_encoder(text_emb: torch.Tensor, mel: torch.Tensor, params: AlignmentEncoderParams,
                       t_x: Optional[torch.Tensor] = None, prior: Optional[torch.Tensor] = None,
-                      want_soft: bool = False):
-    """text_emb [B,C_text,T_text], mel [B,C_mel,T_mel] -> (logp [B,T_text,T_mel], soft or None)."""
+                      want_soft: bool = False, pitched: bool = False):
+    """text_emb [B,C_text,T_text], mel [B,C_mel,T_mel] -> (logp [B,T_text,T_mel], soft or None).  pitched: see soft_attention()."""
     k = encode(text_emb, params.key_proj)
     q = encode(mel, params.query_proj)
-    return soft_attention(k, q, t_x=t_x, prior=prior, temperature=params.temperature, want_soft=want_soft)
+    return soft_attention(k, q, t_x=t_x, prior=prior, temperature=params.temperature, want_soft=want_soft, pitched=pitched)

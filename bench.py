@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 from aligner_amd import _lib, synth  # noqa: E402
 
 B, C_ATT, TX, TY = 64, 80, 200, 1000
+CONTIGUOUS_LOGP = False          # --contiguous-logp: the step's intermediate in the reference's contiguous layout (A-B)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 SIM_KERNEL = "softattn_rt_kernel"     # the similarity kernel configs[1] launches (csrc/softattn.hip: the row-tile form)
 
@@ -57,7 +58,14 @@ class Step:
         self.queries = torch.randn(B, C_ATT, TY, generator=g).to(dev)    # encoded mel   [B,C,Ty]
         self.t_x = torch.full((B,), TX, dtype=torch.int32, device=dev)
         self.t_y = torch.full((B,), TY, dtype=torch.int32, device=dev)
-        self.logp = torch.empty((B, TX, TY), dtype=torch.float32, device=dev)
+        # the step's own intermediate: log-probs with rows on whole 128-byte lines (a pitch of 1024 elements for T_mel = 1000:
+        # aligner_softattn_ld -> aligner_maxpath_ld); --contiguous-logp: the reference's [B,Tx,Ty] layout
+        if CONTIGUOUS_LOGP:
+            self.logp = torch.empty((B, TX, TY), dtype=torch.float32, device=dev)
+        else:
+            from aligner_amd.softattn import pitched_logp
+            self.logp = pitched_logp(B, TX, TY, dev)
+        self.ld = int(self.logp.stride(1))
         self.path = torch.empty((B, TX, TY), dtype=torch.float32, device=dev)
         self.tok = torch.empty((B, TY), dtype=torch.int32, device=dev)
         self.dur = torch.empty((B, TX), dtype=torch.int32, device=dev)
@@ -74,16 +82,15 @@ class Step:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     def softattn(self):
-        _lib.check(self.lib.aligner_softattn_f32(self.keys.data_ptr(), self.queries.data_ptr(), self.t_x.data_ptr(),
-                                                 None, self.logp.data_ptr(), None, self.sa_ws.data_ptr(),
-                                                 self.sa_ws.numel(), B, C_ATT, TX, TY, 0.0005,
-                                                 _lib.SIM_L2, self.stream()))
+        _lib.check(self.lib.aligner_softattn_ld(self.keys.data_ptr(), self.queries.data_ptr(), self.t_x.data_ptr(),
+                                                None, self.logp.data_ptr(), _lib.DT_F32, self.ld, None, self.sa_ws.data_ptr(),
+                                                self.sa_ws.numel(), B, C_ATT, TX, TY, 0.0005,
+                                                _lib.SIM_L2, self.stream()))
 
     def forward(self):
-        _lib.check(self.lib.aligner_maxpath_forward_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(),
-                                                        self.t_y.data_ptr(), self.tok.data_ptr(), self.dur_out.data_ptr(),
-                                                        self.ws.data_ptr(), self.ws.numel(), B, TX, TY, -1e9, 0,
-                                                        self.stream()))
+        _lib.check(self.lib.aligner_maxpath_ld(self.logp.data_ptr(), _lib.DT_F32, self.ld, self.t_x.data_ptr(),
+                                               self.t_y.data_ptr(), None, 0, self.tok.data_ptr(), self.dur_out.data_ptr(),
+                                               self.ws.data_ptr(), self.ws.numel(), B, TX, TY, -1e9, 0, self.stream()))
 
     def expand(self):
         _lib.check(self.lib.aligner_maxpath_expand_ex(self.ws.data_ptr(), self.path.data_ptr(), _lib.DT_F32, B, TX, TY,
@@ -99,18 +106,18 @@ class Step:
 
     def forward_with_ones(self):
         """The search with ALIGNER_F_PATH_PREZEROED: the kernel writes the path's ones into zeros that are already there."""
-        _lib.check(self.lib.aligner_maxpath_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(), self.t_y.data_ptr(),
-                                                self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
-                                                self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
-                                                -1e9, _lib.F_PATH_PREZEROED, self.stream()))
+        _lib.check(self.lib.aligner_maxpath_ld(self.logp.data_ptr(), _lib.DT_F32, self.ld, self.t_x.data_ptr(), self.t_y.data_ptr(),
+                                               self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
+                                               self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
+                                               -1e9, _lib.F_PATH_PREZEROED, self.stream()))
 
     def search_with_path(self):
         """aligner_maxpath_f32 as a caller uses it: ONE launch -- the search, and on the CUs the batch leaves idle the
         zeros of the dense path; the utterances' workgroups write the ones."""
-        _lib.check(self.lib.aligner_maxpath_f32(self.logp.data_ptr(), None, 0, self.t_x.data_ptr(), self.t_y.data_ptr(),
-                                                self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
-                                                self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
-                                                -1e9, self.expand_flags, self.stream()))
+        _lib.check(self.lib.aligner_maxpath_ld(self.logp.data_ptr(), _lib.DT_F32, self.ld, self.t_x.data_ptr(), self.t_y.data_ptr(),
+                                               self.path.data_ptr(), _lib.DT_F32, self.tok.data_ptr(),
+                                               self.dur_out.data_ptr(), self.ws.data_ptr(), self.ws.numel(), B, TX, TY,
+                                               -1e9, self.expand_flags, self.stream()))
 
     def eager(self):
         if self.path_mode == "fused":
@@ -455,7 +462,7 @@ def run_c3(args, world: int):
     out = {}
 
     def step():
-        logp, _ = aligner_amd.alignment_encoder(text, mel, params, t_x=tx)
+        logp, _ = aligner_amd.alignment_encoder(text, mel, params, t_x=tx, pitched=not CONTIGUOUS_LOGP)
         out["logp"] = logp
         out["res"] = aligner_amd.align(logp, tx, ty, want_tok=True)
 
@@ -481,15 +488,16 @@ def run_c3(args, world: int):
         "text encoder conv 512->1024 k3 alone (split pass + conv_gemm_kernel, fp32 out)": (event_time_us(lambda: aligner_amd.softattn.conv1d(text, *params.key_proj[0], relu=True), it, dev), f1),
         "text encoder conv 1024->80 k1 alone (conv_narrow_kernel, fp32 input staged and split in the kernel)": (event_time_us(lambda: aligner_amd.softattn.conv1d(k1, *params.key_proj[1]), it, dev), 2.0 * Bc * Tx * 2 * Ct * Ca),
         "mel encoder, whole stack in one call (conv_narrow_fused_kernel: fp32 input staged and split in the kernel, the three layers in one kernel)": (event_time_us(lambda: aligner_amd.softattn.encode(mel, params.query_proj), it, dev), 2.0 * Bc * Ty * (Cm * 2 * Cm * 3 + 2 * Cm * Cm + Cm * Ca)),
-        "similarity + log-softmax (softattn_rt_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx), it, dev), 2.0 * Bc * Tx * Ty * Ca),
+        "similarity + log-softmax (softattn_rt_kernel)": (event_time_us(lambda: aligner_amd.soft_attention(k, q, t_x=tx, pitched=not CONTIGUOUS_LOGP), it, dev), 2.0 * Bc * Tx * Ty * Ca),
         "alignment search + dense path (maxpath_pipelined_kernel)": (event_time_us(lambda: aligner_amd.align(logp, tx, ty), it, dev), 0.0),
     }
     # beside the step: what an OTA training step adds on the same log-probs -- the forward-sum objective with its gradient
     # (published CTC form and plain form; both sweeps side by side in one launch + a combining pass)
+    flat = logp.contiguous()             # (the objective's kernels take the contiguous layout)
     beside = {
-        "forward-sum loss + gradient, CTC form (blank -1)": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty, blank_logprob=-1.0), it, dev),
-        "forward-sum loss only, CTC form": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty, want_grad=False, blank_logprob=-1.0), it, dev),
-        "forward-sum loss + gradient, plain form": event_time_us(lambda: aligner_amd.forward_sum(logp, tx, ty), it, dev),
+        "forward-sum loss + gradient, CTC form (blank -1)": event_time_us(lambda: aligner_amd.forward_sum(flat, tx, ty, blank_logprob=-1.0), it, dev),
+        "forward-sum loss only, CTC form": event_time_us(lambda: aligner_amd.forward_sum(flat, tx, ty, want_grad=False, blank_logprob=-1.0), it, dev),
+        "forward-sum loss + gradient, plain form": event_time_us(lambda: aligner_amd.forward_sum(flat, tx, ty), it, dev),
     }
     dom = "text encoder conv 512->1024 k3 alone (split pass + conv_gemm_kernel, fp32 out)"     # the step's dominant launch pair
     tfl = stages[dom][1] / (stages[dom][0] * 1e-6) / 1e12
@@ -513,7 +521,7 @@ def run_c3(args, world: int):
                      "not_in_the_step_us": {n: round(v, 2) for n, v in beside.items()}},
     }
     if not args.no_cpu_baseline:
-        line["cpu_baseline"] = _cpu_dp_baseline(logp.cpu().numpy(), np.full(Bc, Tx, np.int32), np.full(Bc, Ty, np.int32),
+        line["cpu_baseline"] = _cpu_dp_baseline(logp.contiguous().cpu().numpy(), np.full(Bc, Tx, np.int32), np.full(Bc, Ty, np.int32),
                                                 "this step's own [64,200,900] log-probs")
     print(json.dumps(line), flush=True)
 
@@ -679,7 +687,12 @@ def main():
                     help="c2 (default): BASELINE configs[1], the headline; c3: configs[2], the full OTA pipeline; c4: configs[3], "
                          "the 512-utterance ragged job; c5: configs[4], long-form bf16 similarity + alignment + boundary search")
     ap.add_argument("--max-duration", type=int, default=32, help="c5: the boundary search's maximum-duration window")
+    ap.add_argument("--contiguous-logp", action="store_true",
+                    help="keep the step's intermediate log-probs contiguous ([B,Tx,Ty], rows of 4000 bytes) instead of at a row "
+                         "pitch of whole 128-byte lines (A-B: the similarity kernel's stores and the search's loads then straddle lines)")
     args = ap.parse_args()
+    global CONTIGUOUS_LOGP
+    CONTIGUOUS_LOGP = bool(args.contiguous_logp)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` started by hand (or by a driver that does not wrap it in torch.distributed.run): start
@@ -990,6 +1003,9 @@ def main():
                        "batch_per_gpu": B, "t_text": TX, "t_mel": TY, "c_att": C_ATT,
                        "launch": "hipGraph" if step.graph is not None else "eager",
                        "batches_in_flight": nstreams,
+                       "intermediate": ("log-probs [B,Tx,Ty] contiguous (--contiguous-logp)" if CONTIGUOUS_LOGP else
+                                        f"log-probs [B,Tx,Ty] at a row pitch of {step.ld} elements (rows on whole 128-byte lines: "
+                                        "aligner_softattn_ld -> aligner_maxpath_ld); inputs and outputs contiguous"),
                        "path_stores": ("non-temporal (ALIGNER_F_STREAM_PATH) with the batches in flight, ordinary in the "
                                        "serial figure" if stream_path else "ordinary"),
                        "dense_path": {"batches_in_flight": args.path_mode, "serial": args.serial_path_mode,

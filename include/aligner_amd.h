@@ -33,7 +33,9 @@ extern "C" {
 
 /* 4: aligner_maxpath_workspace_bytes grew (per-utterance mask verdicts), aligner_fused_align_f32 left the library,
  *    the prepared-weights image of round 4 (old image + the GEMM form's) and the forward-sum / search workspaces of round 4
- *    are what the *_bytes functions of THIS version return: size every buffer with them, never with constants. */
+ *    are what the *_bytes functions of THIS version return: size every buffer with them, never with constants;
+ *    new entry points aligner_softattn_ld / aligner_maxpath_ld (a row pitch for the pipeline's own intermediate) and the
+ *    test flag ALIGNER_F_TEST_IMPATIENT_FIRST_HALF. */
 #define ALIGNER_ABI_VERSION 4
 
 /* error codes */
@@ -178,6 +180,15 @@ int aligner_maxpath(const void *value_dev, int value_dtype,
                     void *workspace_dev, size_t workspace_bytes,
                     int B, int Tx, int Ty,
                     float max_neg_val, int flags, void *stream);
+/* aligner_maxpath for scores with a ROW PITCH of their own: element [b,x,y] at ((b*Tx + x)*ld_value + y), ld_value >= Ty --
+ * what aligner_softattn_ld writes (rows that start on whole 128-byte lines).  Lengths are given, there is no
+ * mask (ALIGNER_F_STRICT_MASK, ALIGNER_F_WRITE_Q: ALIGNER_EINVAL); path / tok / dur are the contiguous outputs of
+ * aligner_maxpath.  The columns Ty .. ld_value-1 are never read into a result. */
+int aligner_maxpath_ld(const void *value_dev, int value_dtype, int ld_value,
+                       const int32_t *t_xs_dev, const int32_t *t_ys_dev,
+                       void *path_out_dev, int path_dtype, int32_t *tok_out_dev, int32_t *dur_out_dev,
+                       void *workspace_dev, size_t workspace_bytes, int B, int Tx, int Ty,
+                       float max_neg_val, int flags, void *stream);
 int aligner_maxpath_forward(const void *value_dev, int value_dtype,
                             const void *mask_dev, int mask_dtype,
                             const int32_t *t_xs_dev, const int32_t *t_ys_dev,
@@ -286,6 +297,17 @@ int aligner_softattn_f32(const float *keys_dev, const float *queries_dev,
                          void *workspace_dev, size_t workspace_bytes,
                          int B, int C, int Tx, int Ty,
                          float temperature, int sim, void *stream);
+/* aligner_softattn with a ROW PITCH for logp_out_dev: element [b,i,j] at ((b*Tx + i)*ld_logp + j), ld_logp >= Ty, rows on
+ * 16-byte boundaries.  For the pipeline's own intermediate (similarity -> alignment search: aligner_maxpath_ld reads it):
+ * with ld_logp a multiple of 32 (fp32) every 32-frame run a wave stores is one whole 128-byte line -- rows of 4000 bytes
+ * (T_mel = 1000) cut three quarters of those runs in two.  Only the columns < Ty are written.  The row-tile
+ * form only (Tx <= 224, C = 80 or 128, Ty % 4 == 0, no prior, no soft output): ALIGNER_EDOM otherwise. */
+int aligner_softattn_ld(const float *keys_dev, const float *queries_dev,
+                        const int32_t *t_xs_dev, const float *prior_dev,
+                        void *logp_out_dev, int logp_dtype, int ld_logp, float *soft_out_dev,
+                        void *workspace_dev, size_t workspace_bytes,
+                        int B, int C, int Tx, int Ty,
+                        float temperature, int sim, void *stream);
 
 /* y[b,o,t] = act( bias[o] + sum_{i,k} w[o,i,k] * x[b,i,t+k-K/2] ), zero padded
  * ("same"), K odd; the 1-D conv of the text / mel encoders. relu: 0 or 1. */

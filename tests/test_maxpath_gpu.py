@@ -341,6 +341,53 @@ def test_strict_mask_verified_on_the_device(dev, request, dt, B, Tx, Ty):
     assert np.array_equal(r.path.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Tx,Ty", [(5, 200, 1000), (3, 70, 264), (2, 300, 808), (9, 33, 136), (2, 130, 999), (1, 1, 40)])
+def test_scores_with_a_row_pitch(dev, dt, B, Tx, Ty):
+    """aligner_maxpath_ld: scores whose rows start on whole 128-byte lines (softattn.pitched_logp -- the layout the pipeline
+    hands from the similarity kernel to the search) give the path, durations and token indices of the contiguous layout,
+    whatever the padding columns hold (here: NaNs).  Ragged lengths, the eight-wave form (300 rows), an odd T_mel (the
+    generic loaders), a NaN among the scores (the exact sweep), the generic kernel, the reference's t_x > t_y walk."""
+    import aligner_amd
+    from aligner_amd.softattn import pitched_logp
+    rng = np.random.default_rng(B * 11 + Tx + Ty)
+    v = torch.from_numpy(rng.standard_normal((B, Tx, Ty)).astype(np.float32) * 3).to(dt)
+    ty = rng.integers(max(Tx, 1), Ty + 1, B).astype(np.int32)
+    tx = np.array([rng.integers(1, Tx + 1) for _ in ty], np.int32)
+    tx[0], ty[0] = Tx, Ty
+    if B > 2:
+        v[2, min(3, Tx - 1), 5] = float("nan")
+    pv = pitched_logp(B, Tx, Ty, dev, dt)
+    ld = pv.stride(1) if Tx > 1 else pv.stride(0)
+    torch.as_strided(pv, (B, Tx, ld), (Tx * ld, ld, 1)).fill_(float("nan"))
+    pv.copy_(v.to(dev))
+    txd, tyd = torch.from_numpy(tx).to(dev), torch.from_numpy(ty).to(dev)
+    for kw in ({}, {"force_generic": True}, {"want_tok": True, "path_dtype": torch.int32}):
+        a = aligner_amd.align(v.to(dev), txd, tyd, **kw)
+        b = aligner_amd.align(pv, txd, tyd, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(a.path, b.path) and torch.equal(a.durations, b.durations), kw
+        if kw.get("want_tok"):
+            assert torch.equal(a.tok, b.tok)
+    want = _oracle_path(v.float().numpy(), tx, ty)
+    assert np.array_equal(b.path.cpu().numpy(), want)
+    if Tx > 4 and B > 1:
+        tx2, ty2 = tx.copy(), ty.copy()
+        tx2[1], ty2[1] = 4, 2                                    # the reference's raw-score walk from row t_x - 1
+        a = aligner_amd.align(v.to(dev), torch.from_numpy(tx2).to(dev), torch.from_numpy(ty2).to(dev), compat_tx_gt_ty=True)
+        b = aligner_amd.align(pv, torch.from_numpy(tx2).to(dev), torch.from_numpy(ty2).to(dev), compat_tx_gt_ty=True)
+        assert torch.equal(a.path, b.path) and torch.equal(a.durations, b.durations)
+    # a mask comes with the reference's contiguous tensors: a pitched value is copied then, never misread -- and the drop-in
+    # call refuses it as the reference's memoryview does (core.c:27843)
+    m = torch.from_numpy(synth.prefix_mask(tx, ty, Tx, Ty)).to(dt).to(dev)
+    a = aligner_amd.align(v.to(dev), mask=m, strict_mask=True)
+    b = aligner_amd.align(pv, mask=m, strict_mask=True)
+    assert torch.equal(a.path, b.path)
+    if not pv.is_contiguous():
+        with pytest.raises(ValueError, match="C-contiguous"):
+            aligner_amd.maximum_path(pv, m)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_sixteen_bit_scores_read_directly(appendix_a, dev, dt):
     """bf16 / fp16 scores go straight into the DP's loaders (no up-cast pass): same path as the fp32 up-cast.

@@ -167,6 +167,38 @@ def test_row_tile_form(dev, request, B, C, Tx, Ty, sim):
     assert torch.equal(b16.cpu(), got.bfloat16().cpu())
 
 
+@pytest.mark.parametrize("B,C,Tx,Ty,sim", RT_SHAPES)
+def test_row_tile_form_with_a_row_pitch(dev, B, C, Tx, Ty, sim):
+    """aligner_softattn_ld: the log-probs at a row pitch of whole 128-byte lines (softattn.pitched_logp, what the pipeline
+    hands from the similarity kernel to the search) -- the same bits as the contiguous layout, fp32 and bf16, and not a
+    byte of the padding columns (or of the canary pitch behind them) touched."""
+    import aligner_amd
+    from aligner_amd.softattn import pitched_logp
+    g = torch.Generator().manual_seed(B * 17 + Tx + Ty)
+    k = torch.randn(B, C, Tx, generator=g).to(dev)
+    q = torch.randn(B, C, Ty, generator=g).to(dev)
+    t_x = torch.randint(1, Tx + 1, (B,), generator=g, dtype=torch.int32).to(dev)
+    temp = 0.0005 if sim == "l2" else 0.11
+    for dt in (torch.float32, torch.bfloat16):
+        flat, _ = aligner_amd.soft_attention(k, q, t_x=t_x, temperature=temp, sim=sim, logp_dtype=dt)
+        out = pitched_logp(B, Tx, Ty, dev, dt)
+        ld = out.stride(1)
+        assert ld % (128 // out.element_size()) == 0 and ld >= Ty and out.stride(0) == Tx * ld
+        whole = torch.as_strided(out, (B, Tx, ld), (Tx * ld, ld, 1))
+        whole.fill_(-7.0)
+        got, _ = aligner_amd.soft_attention(k, q, t_x=t_x, temperature=temp, sim=sim, out=out)
+        torch.cuda.synchronize()
+        assert got.data_ptr() == out.data_ptr()
+        assert torch.equal(got, flat)
+        assert bool((whole[:, :, Ty:] == -7.0).all())
+    # forms without a row pitch of their own say so
+    prior = torch.rand(B, Tx, Ty, generator=g).to(dev)
+    if pitched_logp(B, Tx, Ty, dev).stride(1) != Ty:
+        from aligner_amd._lib import AlignerError
+        with pytest.raises(AlignerError):
+            aligner_amd.soft_attention(k, q, t_x=t_x, prior=prior, out=pitched_logp(B, Tx, Ty, dev))
+
+
 def test_row_tile_form_is_deterministic_under_uneven_load(dev, request):
     """The compute waves take a strip's normaliser from the loader wave through LDS (polled, with their own merge of the
     published statistics as the fall-back): both roads give the same bits, so the result must not depend on timing.
