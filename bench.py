@@ -249,7 +249,9 @@ def cpu_baseline(dev, seconds: float = 12.0):
             s2 += time.perf_counter() - t0
             r2 += 1
         out["all_cores"] = {"value": round(B * r2 / s2, 1), "unit": "utterances/s", "cores": nthr, "kind": "port",
-                            "sample": f"OpenMP batch loop of the C restatement, {r2} batches in {s2:.1f}s"}
+                            "sample": f"OpenMP batch loop of the C restatement, {r2} batches in {s2:.1f}s",
+                            "why_this_many": f"one thread per utterance of the batch (the reference's prange is over the batch, "
+                                             f"core.pyx:44): min(B = {B}, {os.cpu_count()} logical cores)"}
     except Exception as e:  # noqa: BLE001
         out["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
     # secondary line 2: "wrapper-equivalent" -- what a caller of the reference's maximum_path(value,
