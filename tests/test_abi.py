@@ -155,3 +155,28 @@ def test_no_kernel_spills_or_uses_scratch():
     for key in ("softattn_rt_kernel", "maxpath_pipelined_kernel", "expand_kernel", "conv_gemm_kernel", "fwdsum_both_sys_kernel",
                 "fwdsum_backward_sys_kernelILi4ELi16ELb1E"):
         assert any(key in name for _, name, _ in rows), key
+
+
+def test_row_pitch_helpers_and_debug_options_env(built_lib, monkeypatch):
+    """Host logic of the pipeline's row pitch (no GPU): pitched_logp() gives rows on whole 128-byte lines and never touches
+    the reference's layouts; the *_ld entry points refuse a pitch below T_mel and a mask before they look for a device;
+    ALIGNER_DEBUG_OPTIONS rejects a name the library does not know."""
+    import torch
+    from aligner_amd import _lib
+    from aligner_amd.softattn import pitched_logp
+    for (B, Tx, Ty, dt, ld) in [(2, 200, 1000, torch.float32, 1024), (3, 5, 1024, torch.float32, 1024), (2, 7, 4000, torch.bfloat16, 4032),
+                                (1, 1, 36, torch.float32, 64)]:
+        t = pitched_logp(B, Tx, Ty, "cpu", dt)
+        assert tuple(t.shape) == (B, Tx, Ty) and t.stride(2) == 1 and t.stride(1) == ld and t.stride(0) == Tx * ld
+        assert (ld * t.element_size()) % 128 == 0 and (B * Tx == 1 or t.is_contiguous() == (ld == Ty))
+    lib = _lib.load()
+    buf = torch.zeros(64, dtype=torch.float32)
+    p = buf.data_ptr()
+    rc = lib.aligner_softattn_ld(p, p, None, None, p, _lib.DT_F32, 3, None, p, 0, 1, 80, 4, 4, 0.0005, _lib.SIM_L2, None)
+    assert rc == _lib.EINVAL and b"ld_logp" in lib.aligner_last_error()
+    rc = lib.aligner_maxpath_ld(p, _lib.DT_F32, 3, p, p, None, 0, None, None, p, 1 << 20, 1, 4, 4, -1e9, 0, None)
+    assert rc == _lib.EINVAL and b"ld_value" in lib.aligner_last_error()
+    rc = lib.aligner_maxpath_ld(p, _lib.DT_F32, 8, p, p, None, 0, None, None, p, 1 << 20, 1, 4, 4, -1e9, _lib.F_STRICT_MASK, None)
+    assert rc == _lib.EINVAL
+    assert lib.aligner_debug_set_option(b"no_such_option", 1) != 0
+    assert lib.aligner_debug_set_option(b"conv_no_ring", 0) == 0
