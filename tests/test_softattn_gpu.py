@@ -417,6 +417,8 @@ def test_narrow_conv_every_frame_tile(dev, ft):
     (2, 77, (160, 300), (1,)),                     # one layer, 300 output channels (wide form, three output tiles)
     (2, 77, (128, 512, 33), (3, 1)),               # 16 chunks into a k = 1 layer (the group-ring form), ragged frame tile, 33 channels
     (5, 333, (128, 640, 160), (1, 1)),             # 20 chunks, 160 output channels (two tiles a wave), T % 32 != 0
+    (3, 150, (128, 512, 64, 64, 64, 48), (3, 1, 1, 1, 1)),   # the group-ring layer in the middle of a stack: its epilogue writes
+                                                   # the next layer's split image (SPLIT), the last three layers run as one kernel
 ])
 def test_conv_stack_one_call(dev, B, T, chans, ks):
     """aligner_conv_stack_f32 (encode()): the whole stack in one call, layers chained through split images, against the
