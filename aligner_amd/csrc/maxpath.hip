@@ -2044,7 +2044,16 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
 
 template <typename T>
 static int launch_expand(const int *starts, void *path, int B, int Tx, int Ty, T one, bool stream_path, hipStream_t s) {
-    const int rpb = 8;
+    // Rows per workgroup.  Alone, many small workgroups are fastest (8 rows: 8.4 us for the 51 MB of [64,200,1000] fp32; 50 rows:
+    // 9.6).  With ALIGNER_F_STREAM_PATH the caller says that other batches are in flight: then about one workgroup per CU
+    // (50 rows at that shape) -- the same write stream from a quarter of the wave slots, the rest left to the other
+    // batches' kernels: bench.py's three-batch step 34.6-34.9 -> 32.9-33.0 us.
+    int rpb = 8;
+    if (stream_path) {
+        const long long cells = (long long)B * ((Ty + 1023) / 1024) * Tx;
+        const int want = (int)((cells + device_cu_count() - 1) / device_cu_count());
+        rpb = want < 8 ? 8 : (want > Tx ? Tx : want);
+    }
     dim3 grid((Ty + 1023) / 1024, (Tx + rpb - 1) / rpb, B), block(256);
     const bool vec = (Ty % 4 == 0) && ((reinterpret_cast<uintptr_t>(path) % (sizeof(T) * 4)) == 0);
     if (vec && stream_path)
