@@ -1998,7 +1998,18 @@ static int forward_impl(const void *value, int value_dtype, const void *mask, in
                 const size_t pbytes = path_out ? (size_t)B * Tx * Ty * dtype_size(path_dtype) : 0;
                 if (path_out && !path_is_zero && !(flags & ALIGNER_F_SEPARATE_EXPAND) && cus - B >= 32 &&
                     (reinterpret_cast<uintptr_t>(path_out) & 15) == 0 && pbytes % 16 == 0 && dtype_size(path_dtype) > 0) {
+                    // As many zero workgroups as write the zeros in about half the search's time (a CU streams ~50 GB/s, a
+                    // frame of the search takes ~31 ns: bytes / (775 * Ty)), not one per idle CU: the zeros are not needed
+                    // before the outputs, and the CUs they leave alone are other batches' (bench.py, fused form, three batches
+                    // in flight: 36.8-37.7 us a step with all 192, 33.7 with 64 or 128; ONE batch at a time: 55.7 -> 53.7 us;
+                    // 32 are too few: 61 us).  With the mask to verify they all come: the pieces are their work too.
                     p.zero_blocks = cus - B;
+                    if (!opt_mask) {
+                        const long long need = (long long)(pbytes / ((size_t)775 * (size_t)Ty)) + 1;
+                        const int zc = need < 48 ? 48 : (int)(need > cus - B ? cus - B : need);
+                        if (zc < p.zero_blocks) p.zero_blocks = zc;
+                    }
+                    if (g_opt_maxpath_zero_blocks >= 32 && g_opt_maxpath_zero_blocks <= cus - B) p.zero_blocks = g_opt_maxpath_zero_blocks;
                     p.zero_nt = (flags & ALIGNER_F_STREAM_PATH) ? 1 : 0;
                     p.zero_n16 = pbytes / 16;
                     set_path_ones(p, path_out, path_dtype);
