@@ -5,5 +5,13 @@ for r in 1 2; do for v in "$@"; do
 if [ "$v" = "-" ]; then unset ALIGNER_DEBUG_OPTIONS; else export ALIGNER_DEBUG_OPTIONS=$v; fi
 O=gpurun_out/c3ab; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --config c3 --no-cpu-baseline > $O/b.json 2> $O/err
-echo "[$v] $(grep -o 'ms_per_step": [0-9.]*' $O/b.json) $(grep 'conv_narrow_ring\|conv_narrow_kernel<1, 2, 1, false>\|conv_narrow_fused\|conv_gemm_kernel<3, 13, true>' $(find $O/st -name '*kernel_stats.csv' | head -1) | sed 's/(aligner::[A-Za-z]*Params)//; s/"void aligner:://' | cut -d, -f1-6 | awk -F'",' '{split($2,a,","); printf "%s %s x %.1f us | ", $1, a[1], a[3]/1000}')"; rm -rf $O/st
+python3 - "$v" $O/b.json $(find $O/st -name '*kernel_stats.csv' | head -1) <<'PY'
+import csv, json, sys
+tag, bj, st = sys.argv[1:4]
+try: ms = json.load(open(bj))["ms_per_step"]
+except Exception: ms = None
+rows = [r for r in csv.DictReader(open(st)) if "conv_" in r["Name"] or "softattn" in r["Name"] or "maxpath" in r["Name"]]
+print(f"[{tag}] ms/step {ms} | " + " | ".join(f'{r["Name"].split("(")[0].replace("void aligner::", "")[:44]} x{r["Calls"]} {float(r["AverageNs"]) / 1e3:.1f} us' for r in rows[:9]))
+PY
+rm -rf $O/st
 done; done
