@@ -88,6 +88,27 @@ def test_one_rank_rccl_path_of_the_headline_bench():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["pitched", "contiguous"])
+def test_headline_bench_line_in_both_layouts_of_its_intermediate(layout):
+    """`bench.py` as the driver runs it (`--steps 20 --warmup 5`), with the step's log-probs at a row pitch of whole 128-byte
+    lines (the default: aligner_softattn_ld -> aligner_maxpath_ld) and contiguous (`--contiguous-logp`): one JSON line, the
+    reference's path and duration hashes in both, `roofline` and (skipped here) `cpu_baseline` in their places."""
+    import json
+    args = ["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-side-kernels", "--no-repeats"]
+    r = _run(args + (["--contiguous-logp"] if layout == "contiguous" else []), {}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "utterances/s" and d["value"] > 0
+    assert ("row pitch of 1024" in d["config"]["intermediate"]) == (layout == "pitched")
+    g = d["guards"]
+    assert g["path_matches_reference_hash"] is True and g["durations_match_reference_hash"] is True
+    assert all(v is not False for v in g.values())
+    assert d["roofline"]["kernel"] == "softattn_rt_kernel" and 0.2 < d["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.gpu
 def test_c4_as_a_two_rank_job_matches_the_reference_hashes():
     """BASELINE configs[3] (512 ragged utterances, batch-sharded, durations gathered) self-launched with two ranks in the
     rehearsal form (both on GPU 0, gloo): every shard's gathered durations hash to SURVEY Appendix A's values."""
