@@ -106,34 +106,48 @@ __global__ __launch_bounds__(256) void conv_gemm_wprep_kernel(const float *__res
 // activations [B, Cin, T] fp32 -> split channels-last fragments: xs[plane][b][chunk][quarter][slot], slot s = frame
 // s - HALO; slots outside the utterance and channels >= Cin are zero.  One thread per slot: its 8 channel loads are
 // coalesced across the wave (consecutive frames), its two stores are 16 bytes.
+// CS_U slots a thread, 256 apart (every load and store instruction of a wave stays one contiguous run), all their loads in
+// flight before the first is used: with one slot a thread a workgroup lived for one memory round trip and the pass was bound
+// by that, not by bytes (C3, 52 MB: one slot a thread 14.1 us, four 12.1, eight 12.6).
+constexpr int CS_U = 4;
 __global__ __launch_bounds__(256) void conv_split_kernel(const float *__restrict__ x, uint4 *__restrict__ xs, size_t xs_plane,
                                                          int Cin, int T, int S, int nch, int halo, size_t total) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;       // ((b*nch + chunk)*4 + quarter)*S + slot
-    if (idx >= total) return;
-    const int s = (int)(idx % S);
-    const size_t r = idx / S;
-    const int qq = (int)(r & 3), c = (int)((r >> 2) % nch);
-    const size_t b = (r >> 2) / nch;
-    const int t = s - halo;
-    const bool in = t >= 0 && t < T;
-    const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
-    float v[8];
+    const size_t idx0 = (size_t)blockIdx.x * (256 * CS_U) + threadIdx.x;       // ((b*nch + chunk)*4 + quarter)*S + slot
+    float v[CS_U][8];
+    bool in[CS_U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int i = CG_CH * c + 8 * qq + j;
-        const float ld = x[((size_t)b * Cin + (i < Cin ? i : Cin - 1)) * T + tc];   // unconditional, masked afterwards
-        v[j] = (in && i < Cin) ? ld : 0.f;
-    }
-    cg_bf16x8 hv, lv;
+    for (int u = 0; u < CS_U; ++u) {
+        const size_t idx = idx0 + (size_t)u * 256;
+        const size_t ic = idx < total ? idx : total - 1;
+        const int s = (int)(ic % S);
+        const size_t r = ic / S;
+        const int qq = (int)(r & 3), c = (int)((r >> 2) % nch);
+        const size_t b = (r >> 2) / nch;
+        const int t = s - halo;
+        in[u] = t >= 0 && t < T;
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        __bf16 hh, ll;
-        cg_split(v[j], hh, ll);
-        hv[j] = hh;
-        lv[j] = ll;
+        for (int j = 0; j < 8; ++j) {
+            const int i = CG_CH * c + 8 * qq + j;
+            const float ld = x[((size_t)b * Cin + (i < Cin ? i : Cin - 1)) * T + tc];   // unconditional, masked afterwards
+            v[u][j] = i < Cin ? ld : 0.f;
+        }
     }
-    xs[idx] = __builtin_bit_cast(uint4, hv);
-    xs[xs_plane + idx] = __builtin_bit_cast(uint4, lv);
+#pragma unroll
+    for (int u = 0; u < CS_U; ++u) {
+        const size_t idx = idx0 + (size_t)u * 256;
+        if (idx >= total) break;
+        cg_bf16x8 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 hh, ll;
+            cg_split(in[u] ? v[u][j] : 0.f, hh, ll);
+            hv[j] = hh;
+            lv[j] = ll;
+        }
+        xs[idx] = __builtin_bit_cast(uint4, hv);
+        xs[xs_plane + idx] = __builtin_bit_cast(uint4, lv);
+    }
 }
 
 struct ConvGemmParams {
@@ -1049,8 +1063,8 @@ int conv_stack_run(const float *x, const ConvStackLayer *L, int n, float *y, voi
     auto split_pass = [&](const float *src, uint4 *dst, int Cin, int K) -> int {
         const size_t nch = (Cin + CG_CH - 1) / CG_CH, S = (T + 2 * (K / 2) + 15) / 16 * 16;
         const size_t plane = (size_t)B * nch * 4 * S;
-        hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, s, src, dst, plane, Cin, T, (int)S,
-                           (int)nch, K / 2, plane);
+        hipLaunchKernelGGL(conv_split_kernel, dim3((unsigned)((plane + 256 * CS_U - 1) / (256 * CS_U))), dim3(256), 0, s, src, dst, plane,
+                           Cin, T, (int)S, (int)nch, K / 2, plane);
         ALIGNER_HIP_CHECK(hipGetLastError());
         return ALIGNER_OK;
     };
