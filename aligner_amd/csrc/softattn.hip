@@ -863,9 +863,11 @@ __global__ __launch_bounds__((NT + 1) * 64) void softattn_rt_kernel(SoftAttnPara
         b = blockIdx.x / NQ;
         fq = blockIdx.x % NQ;
     }
-    const int f0 = fq * 32 * RT_STRIPS;
-    const int left = p.Ty - f0;
-    const int NS = left >= 32 * RT_STRIPS ? RT_STRIPS : (left + 31) / 32;          // strips of this workgroup (>= 1)
+    // the utterance's strips dealt evenly to its NQ workgroups (T_mel = 900: 29 strips as 8, 7, 7, 7 -- not 8, 8, 8, 5: the
+    // launch ends with its longest workgroup)
+    const int nstrips = (p.Ty + 31) / 32, sbase = nstrips / NQ, srem = nstrips - sbase * NQ;
+    const int NS = sbase + (fq < srem ? 1 : 0);                                    // strips of this workgroup (>= 1, <= RT_STRIPS)
+    const int f0 = 32 * (fq * sbase + (fq < srem ? fq : srem));
     const float *Qb = p.queries + (size_t)b * p.C * p.Ty;
     RT_STAMP(0);
     if (STAMPS && p.stamps && lane == 0)
