@@ -708,13 +708,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.config in ("c3", "c5"):
         if args.steps == SUSTAINED_STEPS and args.warmup == 2000:
-            args.steps, args.warmup = 30, 5              # a step is 0.4-1.5 ms of several launches
+            args.steps, args.warmup = 1000, 100          # a step is 0.2-0.6 ms of several launches: ~0.5 s (30 steps: 227-233 us at
+                                                         # configs[2], the clocks still settling; 3 000: 211 us)
         return run_c3(args, world) if args.config == "c3" else run_c5(args, world)
     if args.config == "c4":
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
         if args.steps == SUSTAINED_STEPS and args.warmup == 2000:
-            args.steps, args.warmup = 50, 5              # a pass is ~0.1-1 ms: keep the default run short
+            args.steps, args.warmup = 500, 50            # a pass is ~0.1-1 ms: keep the default run short
         return run_c4(args, world, rank, local)
     dist = None
     # ALIGNER_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, duration buckets) with one rank
