@@ -198,7 +198,8 @@ class Step:
 def event_time_us(fn, iters: int, dev) -> float:
     """Average duration of `fn` (one launch) over `iters` back-to-back launches, HIP
     events recorded on the stream the kernel is launched on."""
-    fn()
+    for _ in range(max(1, iters // 10)):         # (untimed: a tenth as many launches first)
+        fn()
     torch.cuda.synchronize(dev)
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
@@ -915,10 +916,14 @@ def main():
         n = max(world, 1)
         ups = n * B * args.steps / elapsed
         # ---- per-kernel timing with HIP events on the launch stream (second pass, same buffers) ----
+        # (2 000 back-to-back launches each for the step's three kernels, a tenth as many untimed first.  Launched back to back
+        # with itself the similarity kernel takes 14.4-14.5 us; between a search and a path kernel -- the one-batch-at-a-time
+        # step under rocprofv3, 3 000 steps -- it averages 13.7: `roofline` reports the slower figure.  A HIP event pair per
+        # launch inside the step does not resolve that: two events with nothing between them are 4.8 us apart.)
         it = 50
-        t_sim = event_time_us(step.softattn, it, dev)
-        t_fwd = event_time_us(step.forward, it, dev)
-        t_exp = event_time_us(step.expand, it, dev)
+        t_sim = event_time_us(step.softattn, 2000, dev)
+        t_fwd = event_time_us(step.forward, 2000, dev)
+        t_exp = event_time_us(step.expand, 2000, dev)
         side_on = not args.no_side_kernels
         t_full = event_time_us(step.search_with_path, it, dev) if side_on else float("nan")
         t_zero = event_time_us(step.zero_path, it, dev) if side_on else float("nan")

@@ -4,6 +4,6 @@ VAR=$1; shift
 for r in 1 2; do for v in "$@"; do
 export $VAR=$v
 O=gpurun_out/env_$v; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > $O/b.json 2> $O/err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/st -- python3 bench.py --steps 3000 --warmup 300 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > $O/b.json 2> $O/err
 echo "$VAR=$v: $(grep 'softattn' $(find $O/st -name '*kernel_stats.csv' | head -1) | head -1 | sed 's/.*SoftAttnParams)",//' | cut -d, -f1-6)"; rm -rf $O/st
 done; done

@@ -7,7 +7,7 @@ stats() { f=$(find $O/$1 -name "*kernel_stats.csv" | head -1); cp $f $O/$2; rm -
 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_shaped.json 2> $O/bench_driver_shaped.err
 for s in 2 3 4; do python3 bench.py --streams $s --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams', d['config']['batches_in_flight'], 'ms/step', d['ms_per_step'], 'serial', d.get('serial_ms_per_step'), 'value', d['value'])"; done > $O/streams_sweep.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > $O/bench_streams1.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3000 --warmup 300 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > $O/bench_streams1.json 2> $O/stats.err
 stats stats bench_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 --no-repeats --no-side-kernels > /dev/null 2> $O/pmc_write.err
