@@ -402,7 +402,7 @@ def run_c4(args, world: int, rank: int, local: int):
                              "dp_kernel_us_per_rank": [round(x, 1) for x in dp_all]},
             "durations_match_reference_hashes": ok,
         }
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -527,7 +527,7 @@ def run_c3(args, world: int):
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = _cpu_dp_baseline(logp.contiguous().cpu().numpy(), np.full(Bc, Tx, np.int32), np.full(Bc, Ty, np.int32),
                                                 "this step's own [64,200,900] log-probs")
-    print(json.dumps(line), flush=True)
+    _emit(line)
 
 
 def run_c5(args, world: int):
@@ -623,7 +623,29 @@ def run_c5(args, world: int):
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = _cpu_dp_baseline(synth.synth_value(Bc, Tx, Ty, 5, bits=8, denom=8.0), np.full(Bc, Tx, np.int32),
                                                 np.full(Bc, Ty, np.int32), "the [8,500,4000] scores of SURVEY Appendix A")
-    print(json.dumps(line), flush=True)
+    _emit(line)
+
+
+_JSON_FD = None
+
+
+def _keep_stdout_for_the_json_line() -> None:
+    """Everything a library writes to file descriptor 1 from here on (RCCL prints its version banner there when the first
+    communicator is made, gloo chats there too) goes to stderr; the JSON line goes to the descriptor stdout WAS."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(obj) -> None:
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
 
 
 def _self_launch(n: int) -> None:
@@ -704,6 +726,7 @@ def main():
         # the N ranks ourselves, as fresh child processes, BEFORE anything in this process touches the GPU
         return _self_launch(args.gpus)
 
+    _keep_stdout_for_the_json_line()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -1041,7 +1064,7 @@ def main():
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev)
             out["speedup_vs_cpu_1thread"] = round(ups / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -79,6 +79,7 @@ def test_one_rank_rccl_path_of_the_headline_bench():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    assert r.stdout.strip() == lines[0], "stdout carries the JSON line and nothing else (RCCL's banner goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
     g = d["guards"]
